@@ -1,0 +1,165 @@
+/*
+ * lens_amd.h -- C ABI of liblens_amd.so: the MI355X (gfx950) implementation of the LENS
+ * inference-and-matching hot path.  Plain pointers and sizes only; no torch / HIP types in
+ * the signatures (a HIP stream is passed as an opaque `void *`, 0 = the null stream).
+ *
+ * The reference (AdamDHines/LENS) is pure Python and has no FFI; each entry point below names
+ * the reference code it replaces (paths relative to the reference repository).  INTEGRATION.md
+ * shows the ctypes binding a LENS maintainer would add to call them.
+ *
+ * Conventions
+ *   - every `d_*` pointer is DEVICE memory owned by the caller; `h_*` pointers are host memory.
+ *     The library never allocates, frees or synchronises; all work is enqueued on `stream`.
+ *   - return value: 0 = LENS_OK; negative = argument error (nothing was enqueued);
+ *     positive = hipError_t of the failed launch.  Nothing throws across the boundary.
+ *   - re-entrant, no global state; one host thread per device.
+ *
+ * Data layouts (row-major, last index fastest)
+ *   frames      uint8  [Q][HW]            event-count frames (PNG pixels), HW = roi_dim*roi_dim
+ *   sel         int32  [N]                flat pixel index of input neuron n (centre-pixel conv)
+ *   codes       uint8  [T][N]             threshold codes: input n spikes at step t iff px >= code
+ *   w1t         float  [N][ldw1]          feature_layer.w.weight TRANSPOSED  (weight is [F][N])
+ *   w2t         float  [F][ldw2]          output_layer.w.weight TRANSPOSED   (weight is [P][F]);
+ *                                         ldw2 >= roundup(P, 256), padding columns zero
+ *   events      uint32 [Q][cap]           per-query feature-spike stream, see lens_feature_events
+ *   counts      float  [Q][ldo]           output spike counts = rows of the similarity matrix
+ */
+#ifndef LENS_AMD_H
+#define LENS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LENS_AMD_ABI_VERSION 1
+
+enum {
+    LENS_OK = 0,
+    LENS_ERR_NULL = -1,        /* a required pointer is NULL */
+    LENS_ERR_SIZE = -2,        /* a size / stride argument is out of range */
+    LENS_ERR_UNSUPPORTED = -3, /* valid request outside what the kernels implement (see each function) */
+    LENS_ERR_ALIGN = -4        /* a pointer / leading dimension violates the stated alignment */
+};
+
+/* Status bits written to d_status by lens_feature_events (OR-ed, caller zeroes the word first). */
+#define LENS_STATUS_SPIKE_OVERFLOW 1 /* a per-step spike count needs > 8 significant bits (first: 257): not encodable in the stream */
+
+/* ABI version of the loaded library (== LENS_AMD_ABI_VERSION it was built with). */
+int lens_amd_abi_version(void);
+
+/* Human-readable text for a negative status of this library ("" for others). */
+const char *lens_amd_strerror(int status);
+
+/*
+ * Event list -> count frames.   Replaces lens/collect_data.py:193-199 `create_images`
+ * (twin: lens/tools/manual_eventframe_generator.py:6-11):
+ *     frame = zeros(roi, roi, int); frame[e.y-1, e.x-1] += 1 per event; astype(uint8)
+ * d_xy        int16 [n_events][2]   (x, y) per event, 1-based like the sensor's
+ * d_frame_off int64 [n_frames+1]    events of frame i are [off[i], off[i+1])
+ * d_frames    uint8 [n_frames][roi][roi]  (count mod 256, like the uint8 cast)
+ * d_first_bad int64 scalar, caller sets it to INT64_MAX; receives the smallest event position whose
+ *             (y-1, x-1) is outside [-roi, roi) (torch indexing would raise IndexError there;
+ *             indices in [-roi, -1] wrap like Python's).  Frames are unspecified if it fires.
+ * roi <= 200 (the histogram lives in LDS); larger -> LENS_ERR_UNSUPPORTED.
+ */
+int lens_accumulate_events(const int16_t *d_xy, const int64_t *d_frame_off, int n_frames, int roi,
+                           uint8_t *d_frames, int64_t *d_first_bad, void *stream);
+
+/*
+ * HOST helper: threshold codes of the rate-coding raster.  Replaces the per-item
+ *     torch.manual_seed(50); (torch.rand(T, H*W) < img/255).float()
+ * of lens/src/dataset.py:23,120-121: with U the (constant) rand tensor,
+ *     code[t][n] = min { p in 1..255 : U[t][n] < (float)p / 255.0f }   (255 if none)
+ * so that  (U < px/255)  <=>  (px >= code)  for every uint8 px.
+ * h_u_sel  float [T][N]  the N selected columns of U (host memory)
+ * h_codes  uint8 [T][N]  (host memory)
+ */
+int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_codes);
+
+/* Words of `events` a query needs in the worst case: roundup16(T * max(F, 1)). */
+size_t lens_event_capacity_words(int T, int F);
+
+/*
+ * Frames -> feature-layer spike streams.  Replaces, for a batch of Q queries,
+ *   lens/src/dataset.py:99-127        (normalise + rate-code raster, via `codes`)
+ *   lens/run_model.py:130-137,141     (centre-pixel Conv2d + IAF #1, an exact identity)
+ *   lens/run_model.py:143-144         (feature Linear + sinabs IAF #2), query loop :229-238
+ * Arithmetic: I[f] = ascending-n chain of fmaf(x[n], w1[f][n], acc) from +0 (x binary), then the
+ * sinabs IAF rule (threshold 1, multi-spike, subtract reset, v_min -1).
+ *
+ * Queries are split into `n_streams` contiguous runs.  carry != 0: each run is integrated
+ * sequentially with the membrane state carried from query to query (the reference never resets;
+ * n_streams = 1 is its exact semantics); d_vfeat [n_streams][F] is read at the start and written
+ * at the end.  carry == 0: state is zeroed before every query, d_vfeat is not touched (may be
+ * NULL), n_streams only sets the parallelism (<= 0: one stream per query).
+ *
+ * Output stream of query q, d_events + q*cap_words, d_nwords[q] words (a multiple of 16):
+ *   per time step, the spiking features in ascending f as words
+ *       bits 0-14 f | bit 15 LAST-of-step | bits 16-31 the upper half of float(spike count)
+ *   (a step without spikes is one word {f=0, LAST, count 0}); zero words pad to a multiple of 16.
+ * d_featspk (optional, NULL to skip): float [Q][T][F] dense spike counts.
+ * d_status: int32 word, OR-ed with LENS_STATUS_* bits.
+ * Limits: N <= 1024, F <= 2048, cap_words >= lens_event_capacity_words(T, F).
+ */
+int lens_feature_events(const uint8_t *d_frames, int Q, int HW,
+                        const int32_t *d_sel, int N,
+                        const uint8_t *d_codes, int T,
+                        const float *d_w1t, int F, int ldw1,
+                        float *d_vfeat, int n_streams, int carry,
+                        uint32_t *d_events, int cap_words, uint32_t *d_nwords,
+                        float *d_featspk, int32_t *d_status, void *stream);
+
+/*
+ * Feature-spike streams -> output spike counts (rows of the similarity matrix).  Replaces
+ *   lens/run_model.py:145,155   (output Linear = the place database, + sinabs IAF #3)
+ *   lens/run_model.py:239       (spikes.sum(dim=0)),  query loop :229-246
+ * Event-driven: I[p] = chain of fmaf(count, w2[p][f], acc) over the step's spiking features in
+ * ascending f, which is bit-identical to the dense ascending-f chain.
+ *
+ * d_w2t: [F][ldw2] with ldw2 % 256 == 0, ldw2 >= P, 16-byte aligned, padding columns zero
+ *        (a database shard is simply a column range of this matrix).
+ * n_groups / carry: as n_streams / carry of lens_feature_events (the two calls must use the same
+ *        split).  carry != 0: d_vout [n_groups][ldv] carried state, read and written.
+ * d_counts: float [Q][ldo], ldo >= P; columns >= P are not written.
+ */
+int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *d_nwords, int Q,
+                       const float *d_w2t, int F, int P, int ldw2,
+                       float *d_vout, int ldv, int n_groups, int carry,
+                       float *d_counts, int ldo, void *stream);
+
+/*
+ * Sequence matcher, full matrix.  Replaces lens/run_model.py:248-252:
+ *     S = (conv2d(out[1,1,Q,P], eye(L)) / L).T
+ * but stores it query-major: d_S [Q-L+1][lds], d_S[i][j] = (1/L) * sum_{d<L} counts[i+d][j+d],
+ * j < P-L+1 (the caller transposes for the reference's [place][query] orientation).  L >= 1.
+ */
+int lens_seqmatch(const float *d_counts, int Q, int P, int ldo, int L, float *d_S, int lds, void *stream);
+
+/*
+ * Sequence matcher fused with per-query top-K.  Replaces lens/run_model.py:248-252 followed by
+ * the `S.argsort(0)[-K:]` of lens/src/metrics.py:219, without materialising S.
+ * For query column i < Q-L+1: the K places j < n_places with the largest S[i][j]; ties broken
+ * towards the LARGER place index (what a stable ascending argsort + [-K:] returns).
+ * n_places: number of sequence-matched places this call ranks (P-L+1 on one GPU; for a database
+ *           shard that carries L-1 halo columns, its own place count).
+ * place_offset is added to the reported indices (global index of the shard's first place).
+ * d_topk_idx int32 [Q-L+1][K], d_topk_val float [Q-L+1][K], best first; missing entries (-1, -inf).
+ * 1 <= K <= 64, L >= 1.
+ */
+int lens_seqmatch_topk(const float *d_counts, int Q, int ldo, int n_places, int L, int K, int place_offset,
+                       int32_t *d_topk_idx, float *d_topk_val, void *stream);
+
+/*
+ * Merge R per-shard top-K lists (e.g. after an RCCL all-gather) into one, same ordering rule.
+ * d_idx_in / d_val_in: [R][Qs][K];  d_idx_out / d_val_out: [Qs][K].
+ */
+int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Qs, int K,
+                    int32_t *d_idx_out, float *d_val_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LENS_AMD_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of liblens_amd.so (the C ABI declared in include/lens_amd.h).
+
+There is no CPU fallback: if the shared library is missing or a kernel is launched without a
+GPU the call raises.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+SO_PATH = os.path.join(_PKG, "liblens_amd.so")
+SRC = os.path.join(_PKG, "csrc", "lens_kernels.hip")
+HEADER = os.path.join(ROOT, "include", "lens_amd.h")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+
+_c_p = ctypes.c_void_p
+_i = ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol include/lens_amd.h declares
+SIGNATURES = {
+    "lens_amd_abi_version": (_i, []),
+    "lens_amd_strerror": (ctypes.c_char_p, [_i]),
+    "lens_accumulate_events": (_i, [_c_p, _c_p, _i, _i, _c_p, _c_p, _c_p]),
+    "lens_build_threshold_codes": (_i, [_c_p, _i, _i, _c_p]),
+    "lens_event_capacity_words": (ctypes.c_size_t, [_i, _i]),
+    "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
+                                 _c_p, _i, _c_p, _c_p, _c_p, _c_p]),
+    "lens_output_counts": (_i, [_c_p, _i, _c_p, _i, _c_p, _i, _i, _i, _c_p, _i, _i, _i, _c_p, _i, _c_p]),
+    "lens_seqmatch": (_i, [_c_p, _i, _i, _i, _i, _c_p, _i, _c_p]),
+    "lens_seqmatch_topk": (_i, [_c_p, _i, _i, _i, _i, _i, _i, _c_p, _c_p, _c_p]),
+    "lens_topk_merge": (_i, [_c_p, _c_p, _i, _i, _i, _c_p, _c_p, _c_p]),
+}
+
+_lib = None
+
+
+class LensAmdError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile lens_amd/csrc/lens_kernels.hip -> lens_amd/liblens_amd.so (gfx950)."""
+    if (not force and os.path.exists(SO_PATH)
+            and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(SRC), os.path.getmtime(HEADER))):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def lib():
+    """Load the shared library (once) and attach the prototypes. Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise LensAmdError(
+                f"{SO_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        got = L.lens_amd_abi_version()
+        if got != 1:
+            raise LensAmdError(f"liblens_amd.so ABI version {got}, expected 1")
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    """Turn a C-ABI status into a Python exception (RuntimeError), like SURVEY 8b asks."""
+    if status == 0:
+        return
+    if status < 0:
+        msg = lib().lens_amd_strerror(status).decode()
+        raise LensAmdError(f"{what}: {msg} (status {status})")
+    raise LensAmdError(f"{what}: HIP error {status}")

@@ -1,0 +1,690 @@
+// lens_kernels.hip -- gfx950 (MI355X / CDNA4) kernels and C ABI of liblens_amd.so.
+//
+// The LENS SNN inference-and-matching hot path, written for 64-wide wavefronts:
+//   k_accumulate_events  event list -> uint8 count frames          (LDS histogram, HBM-bound)
+//   k_feature_events     frames -> rate-coded raster -> feature Linear + IAF -> spike streams
+//   k_output_counts      spike streams x place database (LDS weight tile) + IAF -> spike counts
+//   k_seqmatch[_topk]    diagonal sequence filter (+ wave-level top-K selection)
+//   k_topk_merge         merge of per-shard top-K lists
+//
+// Arithmetic contract (DESIGN.md "Numerics"): every Linear output is an ascending-input-index
+// chain of f32 fused multiply-adds from +0 and the IAF update is evaluated literally in f32;
+// both layers are evaluated event-driven, which leaves every chain bit-identical to the dense
+// one because fmaf(0, w, acc) == acc.  Built with -ffp-contract=off: the only fused operations
+// are the explicit __builtin_fmaf calls.
+//
+// Reference lines each kernel replaces are cited in include/lens_amd.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/lens_amd.h"
+
+namespace {
+
+constexpr uint32_t EV_LAST = 0x8000u;   // bit 15: last word of a time step
+constexpr uint32_t EV_FMASK = 0x7fffu;  // bits 0-14: feature index
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// One sinabs IAF step (threshold 1, MultiSpike, MembraneSubtract, min_v_mem -1):
+//   v += I ; s = (v > 0) * trunc(v) ; v -= s ; v = relu(v + 1) - 1
+// floor(max(v, 0)) == (v > 0) * trunc(v) for every finite v.
+__device__ __forceinline__ float iaf_update(float &v, float cur)
+{
+    float vm = v + cur;
+    float s = __builtin_floorf(__builtin_fmaxf(vm, 0.0f));
+    vm = vm - s;
+    float x = __builtin_fmaxf(vm + 1.0f, 0.0f);
+    v = x - 1.0f;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// a1. events -> frames.  One workgroup per frame, uint32 histogram in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_accumulate_events(const int16_t *__restrict__ xy,
+                                                           const int64_t *__restrict__ frame_off, int roi,
+                                                           uint8_t *__restrict__ frames,
+                                                           unsigned long long *__restrict__ first_bad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *bins = reinterpret_cast<uint32_t *>(smem);
+    const int nb = roi * roi;
+    const int fr = blockIdx.x;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) bins[i] = 0u;
+    __syncthreads();
+    const int64_t e0 = frame_off[fr], e1 = frame_off[fr + 1];
+    const uint32_t *ev = reinterpret_cast<const uint32_t *>(xy);
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const uint32_t w = __builtin_nontemporal_load(ev + e);
+        int c = (int)(int16_t)(w & 0xffffu) - 1;   // x - 1
+        int r = (int)(int16_t)(w >> 16) - 1;       // y - 1
+        if (r < -roi || r >= roi || c < -roi || c >= roi) {
+            atomicMin(first_bad, (unsigned long long)e);
+            continue;
+        }
+        if (r < 0) r += roi;
+        if (c < 0) c += roi;
+        atomicAdd(&bins[r * roi + c], 1u);
+    }
+    __syncthreads();
+    uint8_t *out = frames + (size_t)fr * nb;
+    if ((nb & 3) == 0) {
+        for (int i = threadIdx.x; i < (nb >> 2); i += blockDim.x) {
+            const uint4 b = reinterpret_cast<const uint4 *>(bins)[i];
+            reinterpret_cast<uint32_t *>(out)[i] =
+                (b.x & 0xffu) | ((b.y & 0xffu) << 8) | ((b.z & 0xffu) << 16) | ((b.w & 0xffu) << 24);
+        }
+    } else {
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) out[i] = (uint8_t)(bins[i] & 0xffu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a2-a5. frames -> feature-layer spike streams.  One wavefront per query stream.
+//   NPL input registers per lane (input n = i*64 + lane), FPL feature registers per lane
+//   (feature f = j*64 + lane).  USE_LDS: threshold codes and W1^T staged in LDS once per
+//   workgroup and shared by its wavefronts; otherwise both are read through L1/L2.
+// ------------------------------------------------------------------------------------------
+struct FeatArgs {
+    const uint8_t *frames; int Q; int HW;
+    const int32_t *sel; int N;
+    const uint8_t *codes; int T;
+    const float *w1t; int F; int ldw;
+    float *vfeat; int n_streams; int carry;
+    uint32_t *events; int cap; uint32_t *nwords;
+    float *featspk; int32_t *status;
+};
+
+// Wavefronts per workgroup: the staged tables allow one workgroup per CU, so the workgroup is as
+// large as the register budget of the instantiation allows (latency is hidden by wavefronts).
+template <int NPL, int FPL> constexpr int feat_threads() { return (NPL <= 4 && FPL <= 8) ? 1024 : 256; }
+
+template <int NPL, int FPL, bool USE_LDS>
+__global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(FeatArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = NPL * 64, FP = FPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    uint8_t *s_codes = smem;
+    float *s_w = reinterpret_cast<float *>(smem + ((a.T * NP + 15) & ~15));
+    if constexpr (USE_LDS) {
+        for (int i = threadIdx.x; i < a.T * NP; i += blockDim.x) {
+            const int t = i / NP, n = i - t * NP;
+            s_codes[i] = (n < a.N) ? a.codes[(size_t)t * a.N + n] : (uint8_t)255;
+        }
+        for (int i = threadIdx.x; i < a.N * FP; i += blockDim.x) {
+            const int n = i / FP, f = i - n * FP;
+            s_w[i] = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+        }
+        __syncthreads();
+    }
+    const int s = blockIdx.x * nw + wave;
+    if (s >= a.n_streams) return;
+    const int qs = (int)(((long long)s * a.Q) / a.n_streams);
+    const int qe = (int)(((long long)(s + 1) * a.Q) / a.n_streams);
+
+    int32_t selr[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = i * 64 + lane;
+        selr[i] = (n < a.N) ? a.sel[n] : -1;
+    }
+    float v[FPL];
+#pragma unroll
+    for (int j = 0; j < FPL; ++j) {
+        const int f = j * 64 + lane;
+        v[j] = (a.carry && f < a.F) ? a.vfeat[(size_t)s * a.F + f] : 0.0f;
+    }
+    bool overflow = false;
+
+    for (int q = qs; q < qe; ++q) {
+        if (!a.carry) {
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) v[j] = 0.0f;
+        }
+        uint32_t px[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+            px[i] = (selr[i] >= 0) ? (uint32_t)a.frames[(size_t)q * a.HW + selr[i]] : 0u;
+        uint32_t *ev = a.events + (size_t)q * a.cap;
+        uint32_t count = 0;
+        for (int t = 0; t < a.T; ++t) {
+            float acc[FPL];
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                uint32_t code;
+                if constexpr (USE_LDS) {
+                    code = s_codes[t * NP + i * 64 + lane];
+                } else {
+                    const int n = i * 64 + lane;
+                    code = (n < a.N) ? (uint32_t)a.codes[(size_t)t * a.N + n] : 255u;
+                }
+                uint64_t m = __ballot(px[i] >= code);
+                while (m) {   // active inputs in ascending n (wave-uniform loop)
+                    const int n = i * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) {
+                        float w;
+                        if constexpr (USE_LDS) {
+                            w = s_w[n * FP + j * 64 + lane];
+                        } else {
+                            const int f = j * 64 + lane;
+                            w = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+                        }
+                        acc[j] = acc[j] + w;   // == fmaf(1.0f, w, acc): the input spike is exactly 1
+                    }
+                }
+            }
+            float sp[FPL];
+            uint64_t sm[FPL];
+            uint32_t total = 0;
+#pragma unroll
+            for (int j = 0; j < FPL; ++j) {
+                sp[j] = iaf_update(v[j], acc[j]);
+                sm[j] = __ballot(sp[j] > 0.0f);
+                total += (uint32_t)__builtin_popcountll(sm[j]);
+            }
+            if (a.featspk) {
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    const int f = j * 64 + lane;
+                    if (f < a.F) a.featspk[((size_t)q * a.T + t) * a.F + f] = sp[j];
+                }
+            }
+            if (total == 0) {
+                if (lane == 0) ev[count] = EV_LAST;
+                count += 1;
+            } else {
+                uint32_t base = count;
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    if (sp[j] > 0.0f) {
+                        const uint32_t pos = base + lanes_below(sm[j]);
+                        const uint32_t bits = __float_as_uint(sp[j]);
+                        if (bits & 0xffffu) overflow = true;
+                        uint32_t word = (uint32_t)(j * 64 + lane) | (bits & 0xffff0000u);
+                        if (pos == count + total - 1) word |= EV_LAST;
+                        ev[pos] = word;
+                    }
+                    base += (uint32_t)__builtin_popcountll(sm[j]);
+                }
+                count += total;
+            }
+        }
+        const uint32_t pad = (16u - (count & 15u)) & 15u;
+        if ((uint32_t)lane < pad) ev[count + lane] = 0u;
+        if (lane == 0) a.nwords[q] = count + pad;
+    }
+    if (a.carry) {
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            const int f = j * 64 + lane;
+            if (f < a.F) a.vfeat[(size_t)s * a.F + f] = v[j];
+        }
+    }
+    if (overflow) atomicOr(a.status, LENS_STATUS_SPIKE_OVERFLOW);
+}
+
+// ------------------------------------------------------------------------------------------
+// a5-a6. spike streams -> output spike counts.
+//   A workgroup owns a tile of PT = 64*PPL places (their W2^T columns staged in LDS once) and a
+//   group of queries; each wavefront integrates whole queries against the tile, one lane =
+//   PPL consecutive places, membrane potentials and spike counters in registers, the T-step
+//   loop inside the kernel.  The stream is read with scalar loads, 16 words at a time.
+// ------------------------------------------------------------------------------------------
+struct OutArgs {
+    const uint32_t *events; int cap; const uint32_t *nwords; int Q;
+    const float *w2t; int F; int P; int ldw;
+    float *vout; int ldv; int n_groups; int carry;
+    float *counts; int ldo;
+    int ntiles;
+};
+
+template <int PPL> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int PPL>
+__device__ __forceinline__ void vec_unpack(const typename VecT<PPL>::type &x, float (&o)[PPL])
+{
+    if constexpr (PPL == 1) { o[0] = x; }
+    else if constexpr (PPL == 2) { o[0] = x.x; o[1] = x.y; }
+    else { o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; }
+}
+
+template <int PPL, bool W_LDS>
+__global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using vec_t = typename VecT<PPL>::type;
+    constexpr int PT = 64 * PPL;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    const int tile = blockIdx.x % a.ntiles;
+    const int grp = blockIdx.x / a.ntiles;
+    const int p0 = tile * PT;
+
+    if constexpr (W_LDS) {
+        float4 *dst = reinterpret_cast<float4 *>(smem);
+        const int n4 = a.F * (PT / 4);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            const int f = i / (PT / 4), c = i - f * (PT / 4);
+            dst[i] = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
+        }
+        __syncthreads();
+    }
+    const int qs = (int)(((long long)grp * a.Q) / a.n_groups);
+    const int qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
+    const int pl = p0 + lane * PPL;   // first place of this lane
+
+    float v[PPL], cnt[PPL], acc[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) v[k] = 0.0f;
+    if (a.carry) {
+        if (wave != 0) return;   // a carried stream is sequential: one wavefront per tile
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) v[k] = (pl + k < a.P) ? a.vout[(size_t)grp * a.ldv + pl + k] : 0.0f;
+    }
+    const int qstep = a.carry ? 1 : nw;
+    for (int q = qs + (a.carry ? 0 : wave); q < qe; q += qstep) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            if (!a.carry) v[k] = 0.0f;
+            cnt[k] = 0.0f;
+            acc[k] = 0.0f;
+        }
+        const uint32_t *ev = a.events + (size_t)q * a.cap;
+        const int nch = (int)(a.nwords[q] >> 4);
+        for (int c = 0; c < nch; ++c) {
+            uint32_t e[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = ev[c * 16 + i];
+            float w[16][PPL];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t f = e[i] & EV_FMASK;
+                vec_t wv;
+                if constexpr (W_LDS) {
+                    wv = *reinterpret_cast<const vec_t *>(smem + (size_t)f * (PT * 4) + lane * (PPL * 4));
+                } else {
+                    wv = *reinterpret_cast<const vec_t *>(a.w2t + (size_t)f * a.ldw + pl);
+                }
+                vec_unpack<PPL>(wv, w[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float sv = __uint_as_float(e[i] & 0xffff0000u);
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) acc[k] = __builtin_fmaf(sv, w[i][k], acc[k]);
+                if (e[i] & EV_LAST) {
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) {
+                        cnt[k] += iaf_update(v[k], acc[k]);
+                        acc[k] = 0.0f;
+                    }
+                }
+            }
+        }
+        float *o = a.counts + (size_t)q * a.ldo + pl;
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (pl + k < a.P) o[k] = cnt[k];
+    }
+    if (a.carry) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (pl + k < a.P) a.vout[(size_t)grp * a.ldv + pl + k] = v[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7. sequence matcher, full matrix (query-major).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_seqmatch(const float *__restrict__ counts, int Ps, int ldo, int L,
+                                                  float *__restrict__ S, int lds)
+{
+    const int i = blockIdx.y;
+    const float fl = (float)L;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Ps; j += gridDim.x * blockDim.x) {
+        float n = 0.0f;
+        for (int d = 0; d < L; ++d) n += counts[(size_t)(i + d) * ldo + j + d];   // exact: small integers
+        S[(size_t)i * lds + j] = n / fl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-level sorted list, one entry per lane (lane 0 = best), ordered by (n desc, j desc).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool beats(float n1, int j1, float n2, int j2)
+{
+    return n1 > n2 || (n1 == n2 && j1 > j2);
+}
+
+__device__ __forceinline__ void wave_insert(float &ln, int &lj, float cn, int cj, int lane)
+{
+    const uint64_t m = __ballot(beats(cn, cj, ln, lj));   // the beaten entries form a suffix
+    if (m == 0) return;
+    const int pos = __builtin_ctzll(m);
+    const float un = __shfl_up(ln, 1);
+    const int uj = __shfl_up(lj, 1);
+    if (lane > pos) { ln = un; lj = uj; }
+    else if (lane == pos) { ln = cn; lj = cj; }
+}
+
+// a7 + top-K.  One workgroup per query column; wavefronts scan 64-place chunks from the highest
+// place index down (so that later ties never displace earlier ones), keep a private top-64 and
+// merge through LDS.
+__global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__ counts, int ldo, int n_places,
+                                                       int L, int K, int place_offset,
+                                                       int32_t *__restrict__ tk_idx, float *__restrict__ tk_val)
+{
+    __shared__ float s_n[4][64];
+    __shared__ int s_j[4][64];
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    float ln = -1.0f;   // empty entry: loses against every real candidate (n >= 0)
+    int lj = -1;
+    float tn = -1.0f;   // current K-th best
+    int tj = -1;
+    const int nchunks = (n_places + 63) >> 6;
+    for (int c = wave; c < nchunks; c += nw) {
+        const int j = n_places - 1 - (c * 64 + lane);
+        float n = -2.0f;
+        if (j >= 0) {
+            n = 0.0f;
+            for (int d = 0; d < L; ++d) n += counts[(size_t)(i + d) * ldo + j + d];
+        }
+        uint64_t m = __ballot(j >= 0 && beats(n, j, tn, tj));
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const float cn = __shfl(n, b);
+            const int cj = __shfl(j, b);
+            if (beats(cn, cj, tn, tj)) {
+                wave_insert(ln, lj, cn, cj, lane);
+                tn = __shfl(ln, K - 1);
+                tj = __shfl(lj, K - 1);
+            }
+        }
+    }
+    s_n[wave][lane] = ln;
+    s_j[wave][lane] = lj;
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < nw; ++w) {
+        for (int e = 0; e < K; ++e) {
+            const float cn = s_n[w][e];
+            const int cj = s_j[w][e];
+            if (cj < 0) break;
+            if (beats(cn, cj, tn, tj)) {
+                wave_insert(ln, lj, cn, cj, lane);
+                tn = __shfl(ln, K - 1);
+                tj = __shfl(lj, K - 1);
+            }
+        }
+    }
+    if (lane < K) {
+        tk_idx[(size_t)i * K + lane] = (lj >= 0) ? lj + place_offset : -1;
+        tk_val[(size_t)i * K + lane] = (lj >= 0) ? ln / (float)L : -INFINITY;
+    }
+}
+
+// Merge of R per-shard lists: one wavefront per query column; values are compared as stored
+// (they are n/L with one common L, a monotone map of n).
+__global__ void __launch_bounds__(256) k_topk_merge(const int32_t *__restrict__ idx_in, const float *__restrict__ val_in,
+                                                    int R, int Qs, int K,
+                                                    int32_t *__restrict__ idx_out, float *__restrict__ val_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= Qs) return;
+    float ln = -INFINITY;
+    int lj = -1;
+    for (int r = 0; r < R; ++r) {
+        const size_t base = ((size_t)r * Qs + i) * K;
+        for (int e = 0; e < K; ++e) {
+            const int cj = idx_in[base + e];
+            if (cj < 0) break;
+            wave_insert(ln, lj, val_in[base + e], cj, lane);
+        }
+    }
+    if (lane < K) {
+        idx_out[(size_t)i * K + lane] = lj;
+        val_out[(size_t)i * K + lane] = (lj >= 0) ? ln : -INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------
+constexpr int LDS_BUDGET = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
+
+template <typename K>
+int set_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <int NPL, int FPL>
+int launch_feature(const FeatArgs &a, hipStream_t st)
+{
+    constexpr int NP = NPL * 64, FP = FPL * 64;
+    const size_t lds = (((size_t)a.T * NP + 15) & ~(size_t)15) + (size_t)a.N * FP * 4;
+    const int wpb = feat_threads<NPL, FPL>() / 64;   // wavefronts per workgroup sharing the staged tables
+    const int blocks = (a.n_streams + wpb - 1) / wpb;
+    if (lds <= (size_t)LDS_BUDGET - 1024) {
+        auto k = k_feature_events<NPL, FPL, true>;
+        if (int e = set_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(wpb * 64), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((k_feature_events<NPL, FPL, false>), dim3(blocks), dim3(wpb * 64), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
+template <int NPL>
+int dispatch_feature_f(const FeatArgs &a, hipStream_t st)
+{
+    const int fpl = (a.F + 63) / 64;
+    if (fpl <= 1) return launch_feature<NPL, 1>(a, st);
+    if (fpl <= 2) return launch_feature<NPL, 2>(a, st);
+    if (fpl <= 4) return launch_feature<NPL, 4>(a, st);
+    if (fpl <= 8) return launch_feature<NPL, 8>(a, st);
+    return launch_feature<NPL, 32>(a, st);
+}
+
+template <int PPL, bool W_LDS>
+int launch_output(const OutArgs &a, int threads, hipStream_t st)
+{
+    const size_t lds = W_LDS ? (size_t)a.F * 64 * PPL * 4 : 0;
+    auto k = k_output_counts<PPL, W_LDS>;
+    if (int e = set_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.ntiles * a.n_groups)), dim3(threads), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+}   // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int lens_amd_abi_version(void) { return LENS_AMD_ABI_VERSION; }
+
+const char *lens_amd_strerror(int status)
+{
+    switch (status) {
+    case LENS_OK: return "ok";
+    case LENS_ERR_NULL: return "a required pointer is NULL";
+    case LENS_ERR_SIZE: return "a size or stride argument is out of range";
+    case LENS_ERR_UNSUPPORTED: return "request is outside what the kernels implement";
+    case LENS_ERR_ALIGN: return "a pointer or leading dimension violates the required alignment";
+    default: return "";
+    }
+}
+
+int lens_accumulate_events(const int16_t *d_xy, const int64_t *d_frame_off, int n_frames, int roi,
+                           uint8_t *d_frames, int64_t *d_first_bad, void *stream)
+{
+    if (!d_frame_off || !d_frames || !d_first_bad) return LENS_ERR_NULL;
+    if (n_frames < 0 || roi <= 0) return LENS_ERR_SIZE;
+    if (roi > 200) return LENS_ERR_UNSUPPORTED;
+    if (n_frames == 0) return LENS_OK;
+    if (!d_xy) return LENS_ERR_NULL;
+    if ((uintptr_t)d_xy & 3) return LENS_ERR_ALIGN;
+    const size_t lds = (size_t)roi * roi * 4;
+    if (int e = set_lds(k_accumulate_events, lds)) return e;
+    hipLaunchKernelGGL(k_accumulate_events, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, d_xy, d_frame_off,
+                       roi, d_frames, reinterpret_cast<unsigned long long *>(d_first_bad));
+    return (int)hipGetLastError();
+}
+
+int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_codes)
+{
+    if (!h_u_sel || !h_codes) return LENS_ERR_NULL;
+    if (T < 0 || N < 0) return LENS_ERR_SIZE;
+    float th[256];
+    for (int p = 0; p < 256; ++p) th[p] = (float)p / 255.0f;   // dataset.py:23 (f32 true division)
+    for (size_t i = 0; i < (size_t)T * N; ++i) {
+        const float u = h_u_sel[i];
+        int lo = 1, hi = 255;   // smallest p in [1,255] with u < th[p]; th is increasing, th[255] = 1 > u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (u < th[mid]) hi = mid; else lo = mid + 1;
+        }
+        h_codes[i] = (uint8_t)lo;
+    }
+    return LENS_OK;
+}
+
+size_t lens_event_capacity_words(int T, int F)
+{
+    const size_t per_step = (size_t)(F > 1 ? F : 1);
+    return (((size_t)(T > 0 ? T : 0) * per_step) + 15) & ~(size_t)15;
+}
+
+int lens_feature_events(const uint8_t *d_frames, int Q, int HW, const int32_t *d_sel, int N,
+                        const uint8_t *d_codes, int T, const float *d_w1t, int F, int ldw1,
+                        float *d_vfeat, int n_streams, int carry,
+                        uint32_t *d_events, int cap_words, uint32_t *d_nwords,
+                        float *d_featspk, int32_t *d_status, void *stream)
+{
+    if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_events || !d_nwords || !d_status) return LENS_ERR_NULL;
+    if (carry && !d_vfeat) return LENS_ERR_NULL;
+    if (Q < 0 || HW <= 0 || N <= 0 || T <= 0 || F <= 0 || ldw1 < F) return LENS_ERR_SIZE;
+    if ((size_t)cap_words < lens_event_capacity_words(T, F) || (cap_words & 15)) return LENS_ERR_SIZE;
+    if (N > 1024 || F > 2048) return LENS_ERR_UNSUPPORTED;
+    if (Q == 0) return LENS_OK;
+    if (n_streams <= 0 || n_streams > Q) {
+        if (carry && n_streams > Q) return LENS_ERR_SIZE;
+        n_streams = carry ? 1 : Q;
+    }
+    FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, d_vfeat, n_streams, carry ? 1 : 0,
+               d_events, cap_words, d_nwords, d_featspk, d_status};
+    hipStream_t st = (hipStream_t)stream;
+    const int npl = (N + 63) / 64;
+    if (npl <= 1) return dispatch_feature_f<1>(a, st);
+    if (npl <= 2) return dispatch_feature_f<2>(a, st);
+    if (npl <= 4) return dispatch_feature_f<4>(a, st);
+    return dispatch_feature_f<16>(a, st);
+}
+
+int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *d_nwords, int Q,
+                       const float *d_w2t, int F, int P, int ldw2,
+                       float *d_vout, int ldv, int n_groups, int carry,
+                       float *d_counts, int ldo, void *stream)
+{
+    if (!d_events || !d_nwords || !d_w2t || !d_counts) return LENS_ERR_NULL;
+    if (carry && !d_vout) return LENS_ERR_NULL;
+    if (Q < 0 || F <= 0 || P <= 0 || ldw2 < P || ldo < P || cap_words <= 0 || (carry && ldv < P)) return LENS_ERR_SIZE;
+    if ((ldw2 & 255) || ((uintptr_t)d_w2t & 15)) return LENS_ERR_ALIGN;
+    if (F > (int)EV_FMASK) return LENS_ERR_UNSUPPORTED;
+    if (Q == 0) return LENS_OK;
+    hipStream_t st = (hipStream_t)stream;
+
+    // places per lane: the widest tile whose W2^T columns fit in LDS
+    int ppl = 0;
+    for (int c : {4, 2, 1})
+        if ((size_t)F * 64 * c * 4 <= (size_t)LDS_BUDGET - 1024) { ppl = c; break; }
+    const int pt = 64 * (ppl ? ppl : 4);
+    const int ntiles = (P + pt - 1) / pt;
+
+    int threads;
+    if (carry) {
+        if (n_groups <= 0) n_groups = 1;
+        if (n_groups > Q) return LENS_ERR_SIZE;
+        threads = 64;
+    } else {
+        threads = 1024;
+        if (n_groups <= 0) {
+            // enough workgroups to balance 256 CUs, while every wavefront keeps >= 4 queries if it can
+            const int want = (2048 + ntiles - 1) / ntiles;
+            const int most = (Q + 63) / 64;
+            n_groups = want < most ? want : most;
+            if (n_groups < 1) n_groups = 1;
+        }
+        if (n_groups > Q) n_groups = Q;
+    }
+    OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? 1 : 0,
+              d_counts, ldo, ntiles};
+    switch (ppl) {
+    case 4: return launch_output<4, true>(a, threads, st);
+    case 2: return launch_output<2, true>(a, threads, st);
+    case 1: return launch_output<1, true>(a, threads, st);
+    default: return launch_output<4, false>(a, threads, st);
+    }
+}
+
+int lens_seqmatch(const float *d_counts, int Q, int P, int ldo, int L, float *d_S, int lds, void *stream)
+{
+    if (!d_counts || !d_S) return LENS_ERR_NULL;
+    if (L < 1 || Q < L || P < L || ldo < P || lds < P - L + 1) return LENS_ERR_SIZE;
+    const int Ps = P - L + 1, Qs = Q - L + 1;
+    int bx = (Ps + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_seqmatch, dim3(bx, Qs), dim3(256), 0, (hipStream_t)stream, d_counts, Ps, ldo, L, d_S, lds);
+    return (int)hipGetLastError();
+}
+
+int lens_seqmatch_topk(const float *d_counts, int Q, int ldo, int n_places, int L, int K, int place_offset,
+                       int32_t *d_topk_idx, float *d_topk_val, void *stream)
+{
+    if (!d_counts || !d_topk_idx || !d_topk_val) return LENS_ERR_NULL;
+    if (L < 1 || Q < L || n_places < 1 || n_places + L - 1 > ldo || K < 1 || K > 64) return LENS_ERR_SIZE;
+    hipLaunchKernelGGL(k_seqmatch_topk, dim3(Q - L + 1), dim3(256), 0, (hipStream_t)stream, d_counts, ldo, n_places,
+                       L, K, place_offset, d_topk_idx, d_topk_val);
+    return (int)hipGetLastError();
+}
+
+int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Qs, int K,
+                    int32_t *d_idx_out, float *d_val_out, void *stream)
+{
+    if (!d_idx_in || !d_val_in || !d_idx_out || !d_val_out) return LENS_ERR_NULL;
+    if (R < 1 || Qs < 0 || K < 1 || K > 64) return LENS_ERR_SIZE;
+    if (Qs == 0) return LENS_OK;
+    hipLaunchKernelGGL(k_topk_merge, dim3((Qs + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_idx_in, d_val_in, R,
+                       Qs, K, d_idx_out, d_val_out);
+    return (int)hipGetLastError();
+}
+
+}   // extern "C"

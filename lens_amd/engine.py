@@ -1,0 +1,235 @@
+"""Host-side operator layer over the C ABI (include/lens_amd.h).
+
+torch is used only for device memory, streams and the reference's own RNG call; every numeric
+step of the hot path runs in the HIP kernels of liblens_amd.so.  Nothing here falls back to the
+CPU: tensors must live on a ROCm device and the extension must be built.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+INT64_MAX = (1 << 63) - 1
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.LensAmdError(f"{name} must be a device (ROCm) tensor; this build has no CPU path")
+
+
+# --------------------------------------------------------------------------------------------
+# a1: events -> frames                                   (lens/collect_data.py:193-199)
+# --------------------------------------------------------------------------------------------
+def accumulate_events(xy, frame_off, roi):
+    """xy int16 [n_events,2] (x,y 1-based), frame_off int64 [n_frames+1] -> uint8 [n_frames,roi,roi].
+    Raises IndexError where torch indexing in the reference would."""
+    _need_cuda(xy, "xy"); _need_cuda(frame_off, "frame_off")
+    assert xy.dtype == torch.int16 and xy.dim() == 2 and xy.shape[1] == 2 and xy.is_contiguous()
+    assert frame_off.dtype == torch.int64 and frame_off.is_contiguous()
+    n_frames = frame_off.numel() - 1
+    frames = torch.empty((n_frames, roi, roi), dtype=torch.uint8, device=xy.device)
+    bad = torch.full((1,), INT64_MAX, dtype=torch.int64, device=xy.device)
+    st = _lib.lib().lens_accumulate_events(_ptr(xy), _ptr(frame_off), n_frames, roi, _ptr(frames), _ptr(bad), _stream())
+    _lib.check(st, "lens_accumulate_events")
+    b = int(bad.item())
+    if b != INT64_MAX:
+        x, y = (int(v) for v in xy[b].tolist())
+        raise IndexError(f"event {b} (x={x}, y={y}) is out of bounds for a {roi}x{roi} frame")
+    return frames
+
+
+# --------------------------------------------------------------------------------------------
+# a2/a3 host pieces: centre-pixel index and threshold codes
+# --------------------------------------------------------------------------------------------
+def centre_pixel_index(roi_dim, dims):
+    """Flat pixel index read by input neuron n = r*dims + c: the one-hot Conv2d(k, stride k) of
+    lens/run_model.py:130-137 with k = roi_dim // dims and hot tap (k//2 - 1, k//2 - 1)
+    (a negative tap index, k == 1, wraps like Python indexing)."""
+    k = roi_dim // dims
+    c0 = k // 2 - 1
+    if c0 < 0:
+        c0 += k
+    r = np.arange(dims) * k + c0
+    return (r[:, None] * roi_dim + r[None, :]).reshape(-1).astype(np.int32)
+
+
+def rand_tensor(T, HW):
+    """The uniform tensor of lens/src/dataset.py:120-121 (`torch.manual_seed(50); torch.rand(T, H*W)`),
+    drawn from a private CPU generator so the caller's global RNG state is left alone."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(50)
+    return torch.rand(T, HW, generator=g)
+
+
+def build_threshold_codes(T, roi_dim, sel):
+    """uint8 [T,N] codes with  (U[t, sel[n]] < px/255)  <=>  (px >= code[t,n])."""
+    U = rand_tensor(T, roi_dim * roi_dim)
+    u_sel = U[:, torch.as_tensor(np.asarray(sel), dtype=torch.long)].contiguous()
+    codes = torch.empty(u_sel.shape, dtype=torch.uint8)
+    st = _lib.lib().lens_build_threshold_codes(_ptr(u_sel), u_sel.shape[0], u_sel.shape[1], _ptr(codes))
+    _lib.check(st, "lens_build_threshold_codes")
+    return codes
+
+
+# --------------------------------------------------------------------------------------------
+# the SNN forward
+# --------------------------------------------------------------------------------------------
+class LensEngine:
+    """Device-resident LENS network: weights, threshold codes, membrane state and workspaces.
+
+    w1: feature_layer.w.weight [F,N];  w2: output_layer.w.weight [P,F] (or a row range of it for a
+    database shard).  State (`v_feat`, `v_out`) persists across `forward_counts(carry=True)` calls,
+    which is the reference's behaviour (it never resets its IAF layers, lens/run_model.py:234-242).
+    """
+
+    def __init__(self, w1, w2, roi_dim, dims, timebin, device="cuda", max_batch=4096):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.LensAmdError("LensEngine needs a ROCm device; this build has no CPU path")
+        _lib.lib()
+        w1 = torch.as_tensor(w1, dtype=torch.float32)
+        w2 = torch.as_tensor(w2, dtype=torch.float32)
+        self.F, self.N = w1.shape
+        self.P = w2.shape[0]
+        assert w2.shape[1] == self.F and self.N == dims * dims
+        self.roi_dim, self.dims, self.T = int(roi_dim), int(dims), int(timebin)
+        self.HW = self.roi_dim * self.roi_dim
+        self.device = dev
+        self.max_batch = int(max_batch)
+        sel = centre_pixel_index(self.roi_dim, self.dims)
+        self.sel = torch.from_numpy(sel).to(dev)
+        self.codes = build_threshold_codes(self.T, self.roi_dim, sel).to(dev)
+        # transposed, padded weight layouts the kernels read
+        self.w1t = w1.t().contiguous().to(dev)                          # [N][F]
+        self.ldw2 = (self.P + 255) // 256 * 256
+        w2t = torch.zeros((self.F, self.ldw2), dtype=torch.float32, device=dev)
+        w2t[:, :self.P] = w2.t().to(dev)
+        self.w2t = w2t
+        self.cap = int(_lib.lib().lens_event_capacity_words(self.T, self.F))
+        self.n_streams = 1
+        self.reset_state()
+        self._ws_q = 0
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    # ---- state -------------------------------------------------------------------------
+    def reset_state(self, n_streams=1):
+        """Zero the membrane potentials (sinabs' reset_states()); n_streams independent carried runs."""
+        self.n_streams = int(n_streams)
+        self.v_feat = torch.zeros((self.n_streams, self.F), dtype=torch.float32, device=self.device)
+        self.v_out = torch.zeros((self.n_streams, self.P), dtype=torch.float32, device=self.device)
+
+    def _workspace(self, Q):
+        if Q > self._ws_q:
+            self.events = torch.empty((Q, self.cap), dtype=torch.int32, device=self.device)
+            self.nwords = torch.empty((Q,), dtype=torch.int32, device=self.device)
+            self._ws_q = Q
+
+    # ---- kernels -----------------------------------------------------------------------
+    def feature_events(self, frames, carry=False, want_spikes=False):
+        """frames uint8 [Q,H,W] (device) -> fills self.events/self.nwords; optionally returns the dense
+        feature spikes float32 [Q,T,F]."""
+        _need_cuda(frames, "frames")
+        assert frames.dtype == torch.uint8 and frames.is_contiguous()
+        Q = frames.shape[0]
+        assert frames[0].numel() == self.HW, "frame size does not match roi_dim"
+        self._workspace(Q)
+        spk = torch.empty((Q, self.T, self.F), dtype=torch.float32, device=self.device) if want_spikes else None
+        n_streams = self.n_streams if carry else 0
+        st = _lib.lib().lens_feature_events(
+            _ptr(frames), Q, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
+            _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), n_streams, int(carry),
+            _ptr(self.events), self.cap, _ptr(self.nwords), _ptr(spk), _ptr(self.status), _stream())
+        _lib.check(st, "lens_feature_events")
+        return spk
+
+    def output_counts(self, Q, carry=False, n_groups=0, out=None):
+        """Consumes self.events of the last feature_events call -> spike counts float32 [Q,P]."""
+        if out is None:
+            out = torch.empty((Q, self.P), dtype=torch.float32, device=self.device)
+        assert out.shape == (Q, self.P) and out.is_contiguous()
+        groups = self.n_streams if carry else n_groups
+        st = _lib.lib().lens_output_counts(
+            _ptr(self.events), self.cap, _ptr(self.nwords), Q, _ptr(self.w2t), self.F, self.P, self.ldw2,
+            _ptr(self.v_out), self.P, groups, int(carry), _ptr(out), self.P, _stream())
+        _lib.check(st, "lens_output_counts")
+        return out
+
+    def forward_counts(self, frames, carry=False, n_groups=0, check_status=True):
+        """The query loop of LENS.evaluate (lens/run_model.py:229-246) for a batch of frames:
+        uint8 [Q,H,W] -> similarity-matrix rows float32 [Q,P].  carry=True integrates the queries
+        in order with the membrane state carried across them (and across calls)."""
+        Q = frames.shape[0]
+        out = torch.empty((Q, self.P), dtype=torch.float32, device=self.device)
+        step = self.max_batch
+        if carry and self.n_streams > 1 and Q > step:
+            step = Q   # several carried streams split the whole batch; do not re-split it
+        for q0 in range(0, Q, step):
+            fr = frames[q0:q0 + step]
+            self.feature_events(fr, carry=carry)
+            self.output_counts(fr.shape[0], carry=carry, n_groups=n_groups, out=out[q0:q0 + step])
+        if check_status:
+            self.check_status()
+        return out
+
+    def check_status(self):
+        s = int(self.status.item())
+        if s & 1:
+            self.status.zero_()
+            raise _lib.LensAmdError("a feature neuron's per-step spike count needs more than 8 significant bits "
+                                    "(>= 257): outside the exact range of the spike-stream encoding")
+
+    # ---- matching ----------------------------------------------------------------------
+    def seqmatch(self, counts, L):
+        """lens/run_model.py:248-252, query-major: S[i][j] float32 [Q-L+1, P-L+1]."""
+        return seqmatch(counts, L)
+
+    def seqmatch_topk(self, counts, L, K, n_places=None, place_offset=0):
+        return seqmatch_topk(counts, L, K, n_places=n_places, place_offset=place_offset)
+
+
+def seqmatch(counts, L):
+    _need_cuda(counts, "counts")
+    assert counts.dtype == torch.float32 and counts.is_contiguous()
+    Q, P = counts.shape
+    S = torch.empty((Q - L + 1, P - L + 1), dtype=torch.float32, device=counts.device)
+    st = _lib.lib().lens_seqmatch(_ptr(counts), Q, P, P, L, _ptr(S), P - L + 1, _stream())
+    _lib.check(st, "lens_seqmatch")
+    return S
+
+
+def seqmatch_topk(counts, L, K, n_places=None, place_offset=0):
+    """Sequence matcher + top-K per query (ties -> larger place index). counts [Q, ld] device.
+    Returns idx int32 [Q-L+1,K], val float32 [Q-L+1,K]."""
+    _need_cuda(counts, "counts")
+    assert counts.dtype == torch.float32 and counts.is_contiguous()
+    Q, ld = counts.shape
+    if n_places is None:
+        n_places = ld - L + 1
+    idx = torch.empty((Q - L + 1, K), dtype=torch.int32, device=counts.device)
+    val = torch.empty((Q - L + 1, K), dtype=torch.float32, device=counts.device)
+    st = _lib.lib().lens_seqmatch_topk(_ptr(counts), Q, ld, n_places, L, K, place_offset, _ptr(idx), _ptr(val), _stream())
+    _lib.check(st, "lens_seqmatch_topk")
+    return idx, val
+
+
+def topk_merge(idx_in, val_in):
+    """Merge per-shard lists [R,Qs,K] -> [Qs,K] with the same ordering rule."""
+    _need_cuda(idx_in, "idx_in")
+    R, Qs, K = idx_in.shape
+    assert idx_in.dtype == torch.int32 and val_in.dtype == torch.float32
+    idx_in = idx_in.contiguous(); val_in = val_in.contiguous()
+    idx = torch.empty((Qs, K), dtype=torch.int32, device=idx_in.device)
+    val = torch.empty((Qs, K), dtype=torch.float32, device=idx_in.device)
+    st = _lib.lib().lens_topk_merge(_ptr(idx_in), _ptr(val_in), R, Qs, K, _ptr(idx), _ptr(val), _stream())
+    _lib.check(st, "lens_topk_merge")
+    return idx, val

@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bar: bit-exact spike counts / similarity matrices / top-k indices (integer-valued work); the only
+floating-point outputs, S = n/L, must be equal to the oracle's float32 (tolerance 0, stated here).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_config, pretrained_example
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    oracle.lib()
+    return oracle
+
+
+def _engine(w1, w2, roi, dims, T=250, **kw):
+    from lens_amd.engine import LensEngine
+    return LensEngine(w1, w2, roi, dims, T, device="cuda", **kw)
+
+
+@pytest.mark.parametrize("tag", ["example", "sunset"])
+@pytest.mark.parametrize("mode", ["carry", "reset"])
+def test_bundled_counts_match_golden(tag, mode):
+    """Config 1 inputs: out[Q,P] must equal the vectors produced by the reference's own plumbing."""
+    c, frames, w1, w2, gt, G = load_config(tag)
+    eng = _engine(w1, w2, c["roi"], c["dims"])
+    out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=(mode == "carry")).cpu().numpy()
+    assert np.array_equal(out, np.round(out))
+    assert np.array_equal(out.astype(np.int16), G[f"out_{mode}"])
+
+
+@pytest.mark.parametrize("tag", ["example", "sunset"])
+def test_feature_spikes_match_golden(tag):
+    c, frames, w1, w2, gt, G = load_config(tag)
+    eng = _engine(w1, w2, c["roi"], c["dims"])
+    spk = eng.feature_events(torch.from_numpy(frames).cuda(), carry=True, want_spikes=True).cpu().numpy()
+    fq = G["feat_queries"]
+    assert np.array_equal(spk[fq].astype(np.int8), G["feat_spk"])
+
+
+def test_carry_state_persists_across_calls():
+    """Two half-batches with carried state == one full batch (state lives in the engine)."""
+    c, frames, w1, w2, gt, G = load_config("example")
+    eng = _engine(w1, w2, c["roi"], c["dims"])
+    f = torch.from_numpy(frames).cuda()
+    a = eng.forward_counts(f[:37], carry=True)
+    b = eng.forward_counts(f[37:], carry=True)
+    out = torch.cat([a, b]).cpu().numpy()
+    assert np.array_equal(out.astype(np.int16), G["out_carry"])
+    eng.reset_state()
+    again = eng.forward_counts(f, carry=True).cpu().numpy()
+    assert np.array_equal(again.astype(np.int16), G["out_carry"])
+
+
+@pytest.mark.parametrize("tag", ["example", "sunset"])
+def test_seqmatch_and_recall_match_golden(tag, O):
+    c, frames, w1, w2, gt, G = load_config(tag)
+    from lens_amd.engine import seqmatch, seqmatch_topk
+    out = torch.from_numpy(G["out_carry"].astype(np.float32)).cuda()
+    S = seqmatch(out, 2).cpu().numpy().T            # reference orientation [P',Q']
+    assert np.array_equal(S, G["S_carry"])           # float32 equality, tolerance 0
+    GT = O.gt_tolerance(gt, 2, 3)
+    for K in (1, 5, 10, 15, 20, 25):
+        idx, val = seqmatch_topk(out, 2, K)
+        oi, ov = O.topk(G["S_carry"], K)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.array_equal(val.cpu().numpy(), ov)
+        # Recall from the GPU top-k == the reference formula evaluated with a stable argsort
+        assert O.recall_from_topk(idx.cpu().numpy(), GT, K) == O.recall_at_k(G["S_carry"], GT, K, kind="stable")
+
+
+@pytest.mark.parametrize("P,Q,mode", [(1000, 48, "reset"), (1000, 24, "carry"), (300, 40, "reset"), (2500, 16, "reset")])
+def test_synthetic_counts_match_oracle(P, Q, mode, O):
+    """Config 2 shape (128x128 frames, N=100, F=200) at sizes the oracle finishes in seconds."""
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    w2 = synthetic_database(w2p, P).numpy()
+    frames = synthetic_frames(Q, 128, seed=99 + P)
+    eng = _engine(w1, w2, 128, 10)
+    out = eng.forward_counts(frames.cuda(), carry=(mode == "carry")).cpu().numpy()
+    U = O.rand_U(250, 128 * 128)
+    ref = O.forward(frames.numpy(), 10, U, w1, w2, carry=(mode == "carry"), skip_zero=True)
+    assert np.array_equal(out, ref)
+    assert out.sum() > 0
+
+
+def test_multi_stream_carry_matches_oracle(O):
+    """n_streams carried runs == the oracle run separately on each contiguous slice."""
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    w2 = synthetic_database(w2p, 500).numpy()
+    frames = synthetic_frames(30, 128, seed=5)
+    eng = _engine(w1, w2, 128, 10)
+    eng.reset_state(n_streams=3)
+    out = eng.forward_counts(frames.cuda(), carry=True).cpu().numpy()
+    U = O.rand_U(250, 128 * 128)
+    ref = np.concatenate([O.forward(frames.numpy()[s * 10:(s + 1) * 10], 10, U, w1, w2, carry=True, skip_zero=True)
+                          for s in range(3)])
+    assert np.array_equal(out, ref)
+
+
+def test_odd_sizes_and_wide_layers(O):
+    """Ragged sizes: N=49 (one partial register), F=63, P=641 already covered by sunset; here a wide
+    feature layer (F=520 -> 16 registers/lane rounds to the 32 variant) and N=144."""
+    rng = np.random.default_rng(3)
+    dims, roi, T = 12, 36, 40
+    N, F, P, Q = dims * dims, 520, 77, 6
+    w1 = (rng.standard_normal((F, N)) * 0.6).astype(np.float32)
+    w2 = (rng.standard_normal((P, F)) * 0.05).astype(np.float32)
+    frames = rng.integers(0, 60, size=(Q, roi, roi)).astype(np.uint8)
+    eng = _engine(w1, w2, roi, dims, T=T)
+    out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=True).cpu().numpy()
+    U = O.rand_U(T, roi * roi)
+    ref = O.forward(frames, dims, U, w1, w2, carry=True)
+    assert np.array_equal(out, ref)
+
+
+def test_empty_and_saturated_frames(O):
+    """All-zero frames never spike; all-255 frames spike every step (px >= code always)."""
+    w1, w2 = pretrained_example()
+    frames = np.zeros((4, 80, 80), np.uint8)
+    frames[1] = 255
+    frames[3] = 255
+    eng = _engine(w1, w2, 80, 10)
+    out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=True).cpu().numpy()
+    U = O.rand_U(250, 6400)
+    ref = O.forward(frames, 10, U, w1, w2, carry=True)
+    assert np.array_equal(out, ref)
+    assert out[0].sum() == 0
+
+
+def test_spike_overflow_is_reported():
+    """A per-step spike count with more than 8 significant bits (257) cannot be encoded in the stream:
+    the engine must raise, not return wrong counts."""
+    from lens_amd._lib import LensAmdError
+    dims, roi, T = 2, 2, 4
+    w1 = np.full((3, 4), 64.25, np.float32)      # 4 inputs * 64.25 -> 257 spikes in one step
+    w2 = np.zeros((5, 3), np.float32)
+    eng = _engine(w1, w2, roi, dims, T=T)
+    frames = np.full((1, 2, 2), 255, np.uint8)
+    with pytest.raises(LensAmdError):
+        eng.forward_counts(torch.from_numpy(frames).cuda(), carry=False)
+
+
+def test_topk_ties_and_short_lists(O):
+    """Heavy ties (scores in {0,1,2}) and K larger than the number of places."""
+    from lens_amd.engine import seqmatch_topk
+    rng = np.random.default_rng(11)
+    out = rng.integers(0, 3, size=(9, 700)).astype(np.float32)
+    for L in (1, 2, 3):
+        S = O.seqmatch(out, L)
+        for K in (1, 25, 64):
+            idx, val = seqmatch_topk(torch.from_numpy(out).cuda(), L, K)
+            oi, ov = O.topk(S, K)
+            assert np.array_equal(idx.cpu().numpy(), oi)
+            assert np.array_equal(val.cpu().numpy(), ov)
+    small = rng.integers(0, 3, size=(4, 10)).astype(np.float32)
+    idx, val = seqmatch_topk(torch.from_numpy(small).cuda(), 2, 25)
+    oi, ov = O.topk(O.seqmatch(small, 2), 25)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(val.cpu().numpy(), ov)
+
+
+def test_sharded_topk_merge_equals_unsharded(O):
+    """Place shards with an (L-1)-column halo, local top-k with global indices, merge == global."""
+    from lens_amd.engine import seqmatch_topk, topk_merge
+    rng = np.random.default_rng(2)
+    Q, P, L, K, R = 33, 1000, 2, 25, 8
+    out = rng.integers(0, 6, size=(Q, P)).astype(np.float32)
+    full_i, full_v = seqmatch_topk(torch.from_numpy(out).cuda(), L, K)
+    Ps = P - L + 1
+    bounds = [r * Ps // R for r in range(R + 1)]
+    parts_i, parts_v = [], []
+    for r in range(R):
+        p0, p1 = bounds[r], bounds[r + 1]
+        shard = np.ascontiguousarray(out[:, p0:p1 + L - 1])
+        i, v = seqmatch_topk(torch.from_numpy(shard).cuda(), L, K, n_places=p1 - p0, place_offset=p0)
+        parts_i.append(i); parts_v.append(v)
+    mi, mv = topk_merge(torch.stack(parts_i), torch.stack(parts_v))
+    assert torch.equal(mi, full_i) and torch.equal(mv, full_v)
+
+
+def test_accumulate_events_matches_oracle(O):
+    from lens_amd.engine import accumulate_events
+    from lens_amd.synthetic import synthetic_frames, synthetic_events
+    frames = synthetic_frames(5, 128, seed=8)
+    frames[2] = 0                                   # a window without events
+    frames[3, 10, 20] = 255                         # saturate, then push past the uint8 wrap below
+    xy, off = synthetic_events(frames)
+    extra = torch.tensor([[21, 11]] * 3, dtype=torch.int16)   # 3 more events on pixel (10,20) of frame 4
+    xy = torch.cat([xy, extra]); off[-1] += 3
+    got = accumulate_events(xy.cuda(), off.cuda(), 128).cpu().numpy()
+    ref = O.accumulate_events(xy.numpy()[:, 0], xy.numpy()[:, 1], off.numpy(), 128)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got[:4], frames.numpy()[:4])
+    # wrap-around of the uint8 cast: 256 events on one pixel -> 0
+    xyw = torch.tensor([[5, 7]] * 256, dtype=torch.int16)
+    offw = torch.tensor([0, 256], dtype=torch.int64)
+    gw = accumulate_events(xyw.cuda(), offw.cuda(), 16).cpu().numpy()
+    assert gw[0, 6, 4] == 0 and gw.sum() == 0
+    # python-style negative index (x = 0 -> column -1) and an out-of-range event
+    xyn = torch.tensor([[0, 1]], dtype=torch.int16)
+    gn = accumulate_events(xyn.cuda(), torch.tensor([0, 1]).cuda(), 16).cpu().numpy()
+    assert gn[0, 0, 15] == 1
+    with pytest.raises(IndexError):
+        accumulate_events(torch.tensor([[17, 1]], dtype=torch.int16).cuda(), torch.tensor([0, 1]).cuda(), 16)
+    with pytest.raises(IndexError):
+        O.accumulate_events(np.array([17], np.int16), np.array([1], np.int16), np.array([0, 1]), 16)

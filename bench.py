@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the LENS hot path on MI355X (contract: see the round prompt / DESIGN.md "Measurement").
+
+A step = one pass of the hot path over one batch of synthetic 128x128 event-count frames already
+resident in HBM:   frames -> rate-coded feature spike streams -> event-driven output layer (place
+database) -> sequence matcher + top-25 per query  [-> RCCL all-gather + merge when the database is
+sharded].  Metric: query event-frames/s (BASELINE.json), whole job.
+
+  python bench.py                                  config 2: 1k-place DB, 4096 queries, 1 GPU
+  python bench.py --places 100000                  config 3: 100k-place DB on one GPU
+  torchrun ... bench.py --gpus 8                   default: queries sharded over ranks (weak, no collective)
+  torchrun ... bench.py --gpus 8 --places 100000 --shard db     config 4: DB sharded, all-gather of top-k
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3     # MI355X fp32, vector == f32-MFMA rate (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0        # HBM3E spec (same guide)
+T_STEPS, ROI, DIMS, SEQ_L, TOPK = 250, 128, 10, 2, 25
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--places", type=int, default=1000, help="reference DB size P (1000 = config 2, 100000 = config 3/4)")
+    ap.add_argument("--queries", type=int, default=4096, help="query frames per step per rank-batch")
+    ap.add_argument("--shard", choices=["auto", "queries", "db"], default="auto",
+                    help="multi-GPU split: queries (replicated DB, no collective) or db (sharded DB + all-gather)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def pretrained():
+    sd = torch.load(os.path.join(ROOT, "lens", "models", "example-reference_LENS_IN100_FN200_DB100.pth"),
+                    map_location="cpu", weights_only=True)
+    return sd["feature_layer.w.weight"], sd["output_layer.w.weight"]
+
+
+def cpu_baseline(frames, w1, w2, target_cpu_seconds=15.0):
+    """The CPU oracle (a port of the reference path, dense Linear layers, state reset per query like the
+    GPU run) timed on this host's cores on a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    cores = min(os.cpu_count() or 1, 64)
+    U = O.rand_U(T_STEPS, ROI * ROI)
+    f = frames.numpy()
+    w1n, w2n = w1.numpy(), w2.numpy()
+    t0 = time.perf_counter()
+    O.forward(f[:2], DIMS, U, w1n, w2n, carry=False)
+    tq = (time.perf_counter() - t0) / 2
+    n = int(max(cores, min(len(f), target_cpu_seconds / max(tq, 1e-6))))
+    n = min(n, len(f))
+    chunks = [c for c in np.array_split(np.arange(n), cores) if len(c)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(len(chunks)) as ex:       # ctypes releases the GIL inside the C call
+        list(ex.map(lambda c: O.forward(f[c[0]:c[-1] + 1], DIMS, U, w1n, w2n, carry=False), chunks))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "query event-frames/s", "cores": len(chunks), "kind": "port",
+            "sample": f"{n} of the {len(f)} synthetic queries against the same {w2.shape[0]}-place DB, "
+                      f"oracle/lens_oracle.c dense path, one thread per core"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lens_amd.engine import LensEngine, seqmatch_topk, topk_merge
+    from lens_amd.dist import shard_rows, gather_topk
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+
+    shard = a.shard
+    if shard == "auto":
+        shard = "db" if (world > 1 and a.places // world >= 8192) else "queries"
+    if world == 1:
+        shard = "queries"
+
+    w1, w2p = pretrained()
+    w2 = synthetic_database(w2p, a.places)
+    Q = a.queries
+    if shard == "queries":
+        frames_cpu = synthetic_frames(Q, ROI, seed=1234 + rank)     # every rank its own queries
+        eng = LensEngine(w1, w2, ROI, DIMS, T_STEPS, device=dev, max_batch=Q)
+        n_places, offset = a.places - SEQ_L + 1, 0
+        total_queries = Q * world
+    else:
+        frames_cpu = synthetic_frames(Q, ROI, seed=1234)            # same queries, DB split over ranks
+        r0, r1, n_places, offset = shard_rows(a.places, SEQ_L, rank, world)
+        eng = LensEngine(w1, w2[r0:r1], ROI, DIMS, T_STEPS, device=dev, max_batch=Q)
+        total_queries = Q
+    frames = frames_cpu.to(dev)
+
+    names = ["k_feature_events", "k_output_counts", "k_seqmatch_topk"]
+
+    def step(evs=None):
+        if evs is not None: evs[0].record()
+        eng.feature_events(frames, carry=False)
+        if evs is not None: evs[1].record()
+        counts = eng.output_counts(Q, carry=False)
+        if evs is not None: evs[2].record()
+        idx, val = seqmatch_topk(counts, SEQ_L, TOPK, n_places=n_places, place_offset=offset)
+        if evs is not None: evs[3].record()
+        if shard == "db":
+            ia, va = gather_topk(idx, val)
+            idx, val = topk_merge(ia, va)
+        return idx, val
+
+    for _ in range(a.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        idx, val = step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    eng.check_status()
+
+    if rank == 0:
+        ms = [[ev[i].elapsed_time(ev[i + 1]) for ev in events] for i in range(3)]
+        avg_ms = [float(np.mean(m)) for m in ms]
+        dom = int(np.argmax(avg_ms))
+        P_local = eng.P
+        words = float(eng.nwords[:Q].float().mean().item())
+        # algorithmic work per launch (DESIGN.md "Measurement"): dense-equivalent FLOPs of the Linear layers
+        flops = [2.0 * T_STEPS * eng.N * eng.F * Q, 2.0 * T_STEPS * eng.F * P_local * Q, None]
+        # algorithmic bytes per launch for the memory-side kernels
+        byts = [Q * (ROI * ROI + 4.0 * words), None, Q * (SEQ_L * 4.0 * P_local + 8.0 * TOPK)]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(f"P{a.places}_Q{Q}", {}).get(names[dom])
+        if flops[dom] is not None:
+            ach = flops[dom] / (avg_ms[dom] * 1e-3) / 1e12
+            roof = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
+                    "note": "fp32 peak (vector rate == f32 MFMA rate); achieved counts dense-equivalent FLOPs "
+                            "2*T*F*P per query, the kernel executes only the non-zero spikes (event-driven)",
+                    "avg_launch_ms": avg_ms[dom]}
+        else:
+            ach = byts[dom] / (avg_ms[dom] * 1e-3) / 1e9
+            roof = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms[dom]}
+        line = {
+            "metric": "query event-frames/sec vs ref-DB size; Recall@1 parity with reference",
+            "value": total_queries * a.steps / elapsed,
+            "unit": "query event-frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if shard == "db" else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"config {2 if a.places == 1000 else 3 if world == 1 else 4}: pretrained LENS feature layer "
+                                   f"(IN100/FN200), synthetic {ROI}x{ROI} event frames, {a.places}-place reference DB, "
+                                   f"state reset per query, T={T_STEPS}, L={SEQ_L}, top-{TOPK}",
+                       "places": a.places, "queries_per_step": total_queries, "shard": shard if world > 1 else "none",
+                       "feature_spike_words_per_query": words},
+            "kernels_ms": dict(zip(names, avg_ms)),
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(frames_cpu, w1, w2 if shard == "queries" else w2)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

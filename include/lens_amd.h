@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 1
+#define LENS_AMD_ABI_VERSION 2
 
 enum {
     LENS_OK = 0,
@@ -43,9 +43,6 @@ enum {
     LENS_ERR_UNSUPPORTED = -3, /* valid request outside what the kernels implement (see each function) */
     LENS_ERR_ALIGN = -4        /* a pointer / leading dimension violates the stated alignment */
 };
-
-/* Status bits written to d_status by lens_feature_events (OR-ed, caller zeroes the word first). */
-#define LENS_STATUS_SPIKE_OVERFLOW 1 /* a per-step spike count needs > 8 significant bits (first: 257): not encodable in the stream */
 
 /* ABI version of the loaded library (== LENS_AMD_ABI_VERSION it was built with). */
 int lens_amd_abi_version(void);
@@ -79,8 +76,13 @@ int lens_accumulate_events(const int16_t *d_xy, const int64_t *d_frame_off, int 
  */
 int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_codes);
 
-/* Words of `events` a query needs in the worst case: roundup16(T * max(F, 1)). */
+/* Words of `events` a query needs in the worst case: roundup16(2 * T * max(F, 1)). */
 size_t lens_event_capacity_words(int T, int F);
+
+/* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F) can consume
+ * its streams: the byte stride of one W2^T row in the output kernel's LDS tile (1 if the tile does
+ * not fit in LDS and the weights are read through L2). */
+int lens_event_scale(int F);
 
 /*
  * Frames -> feature-layer spike streams.  Replaces, for a batch of Q queries,
@@ -97,20 +99,19 @@ size_t lens_event_capacity_words(int T, int F);
  * NULL), n_streams only sets the parallelism (<= 0: one stream per query).
  *
  * Output stream of query q, d_events + q*cap_words, d_nwords[q] words (a multiple of 16):
- *   per time step, the spiking features in ascending f as words
- *       bits 0-14 f | bit 15 LAST-of-step | bits 16-31 the upper half of float(spike count)
- *   (a step without spikes is one word {f=0, LAST, count 0}); zero words pad to a multiple of 16.
+ *   per time step, the spiking features in ascending f as two-word events
+ *       word 0 = f * ev_scale,  word 1 = float(spike count), sign bit set on the LAST event of the step
+ *   (a step without spikes is one event {0, -0.0f}); null events {0, +0.0f} pad to a multiple of 16 words.
  * d_featspk (optional, NULL to skip): float [Q][T][F] dense spike counts.
- * d_status: int32 word, OR-ed with LENS_STATUS_* bits.
- * Limits: N <= 1024, F <= 2048, cap_words >= lens_event_capacity_words(T, F).
+ * Limits: N <= 1024, F <= 2048, cap_words >= lens_event_capacity_words(T, F), ev_scale * F < 2^31.
  */
 int lens_feature_events(const uint8_t *d_frames, int Q, int HW,
                         const int32_t *d_sel, int N,
                         const uint8_t *d_codes, int T,
                         const float *d_w1t, int F, int ldw1,
                         float *d_vfeat, int n_streams, int carry,
-                        uint32_t *d_events, int cap_words, uint32_t *d_nwords,
-                        float *d_featspk, int32_t *d_status, void *stream);
+                        uint32_t *d_events, int cap_words, uint32_t *d_nwords, int ev_scale,
+                        float *d_featspk, void *stream);
 
 /*
  * Feature-spike streams -> output spike counts (rows of the similarity matrix).  Replaces

@@ -13,7 +13,11 @@ SO_PATH = os.path.join(_PKG, "liblens_amd.so")
 SRC = os.path.join(_PKG, "csrc", "lens_kernels.hip")
 HEADER = os.path.join(ROOT, "include", "lens_amd.h")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+# -ffp-contract=off: the only fused operations are the explicit fmaf calls (numerics contract).
+# -fno-slp-vectorize: packed f32 VALU ops run at half rate on gfx950 (no gain over two plain ops) and
+#   cannot take the |x| source modifier the event loop relies on.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+               "-fPIC", "-shared", "-Wall"]
 
 _c_p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -25,8 +29,9 @@ SIGNATURES = {
     "lens_accumulate_events": (_i, [_c_p, _c_p, _i, _i, _c_p, _c_p, _c_p]),
     "lens_build_threshold_codes": (_i, [_c_p, _i, _i, _c_p]),
     "lens_event_capacity_words": (ctypes.c_size_t, [_i, _i]),
+    "lens_event_scale": (_i, [_i]),
     "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
-                                 _c_p, _i, _c_p, _c_p, _c_p, _c_p]),
+                                 _c_p, _i, _c_p, _i, _c_p, _c_p]),
     "lens_output_counts": (_i, [_c_p, _i, _c_p, _i, _c_p, _i, _i, _i, _c_p, _i, _i, _i, _c_p, _i, _c_p]),
     "lens_seqmatch": (_i, [_c_p, _i, _i, _i, _i, _c_p, _i, _c_p]),
     "lens_seqmatch_topk": (_i, [_c_p, _i, _i, _i, _i, _i, _i, _c_p, _c_p, _c_p]),
@@ -34,6 +39,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2
 
 
 class LensAmdError(RuntimeError):
@@ -67,8 +73,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         got = L.lens_amd_abi_version()
-        if got != 1:
-            raise LensAmdError(f"liblens_amd.so ABI version {got}, expected 1")
+        if got != ABI_VERSION:
+            raise LensAmdError(f"liblens_amd.so ABI version {got}, expected {ABI_VERSION}")
         _lib = L
     return _lib
 

@@ -22,8 +22,12 @@
 
 namespace {
 
-constexpr uint32_t EV_LAST = 0x8000u;   // bit 15: last word of a time step
-constexpr uint32_t EV_FMASK = 0x7fffu;  // bits 0-14: feature index
+// Spike-stream event = two 32-bit words:
+//   word 0: f * ev_scale   (ev_scale = byte stride of one W2^T row in the output kernel's LDS tile, so the
+//           word is the LDS byte offset of feature f's weights; 1 for the non-LDS variant)
+//   word 1: float(spike count) with the sign bit set on the LAST event of a time step (counts are >= 0, the
+//           consumer uses |word 1|).  A step without spikes is one event {0, -0.0f}; {0, +0.0f} pads.
+constexpr uint32_t EV_LAST = 0x80000000u;
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 {
@@ -41,6 +45,17 @@ __device__ __forceinline__ float iaf_update(float &v, float cur)
     float x = __builtin_fmaxf(vm + 1.0f, 0.0f);
     v = x - 1.0f;
     return s;
+}
+
+// The lower clip v = relu(vm + 1) - 1 in two full-rate instructions (v_max_f32 is half rate on gfx950):
+//   h = clamp(fma(vm, 0.5, 0.5), 0, 1) == 0.5 * relu(fl(vm + 1))   exactly (scaling by 0.5 commutes with the
+//       rounding; the upper clamp never binds because vm < 1 here, so fl(vm + 1) <= 2)
+//   v = fma(h, 2, -1)                  == fl(relu(fl(vm + 1)) - 1)
+__device__ __forceinline__ float iaf_clip(float vm)
+{
+    float h;
+    asm("v_fma_f32 %0, %1, 0.5, 0.5 clamp" : "=v"(h) : "v"(vm));
+    return __builtin_fmaf(h, 2.0f, -1.0f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -96,8 +111,8 @@ struct FeatArgs {
     const uint8_t *codes; int T;
     const float *w1t; int F; int ldw;
     float *vfeat; int n_streams; int carry;
-    uint32_t *events; int cap; uint32_t *nwords;
-    float *featspk; int32_t *status;
+    uint32_t *events; int cap; uint32_t *nwords; int ev_scale;
+    float *featspk;
 };
 
 // Wavefronts per workgroup: the staged tables allow one workgroup per CU, so the workgroup is as
@@ -142,8 +157,6 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
         const int f = j * 64 + lane;
         v[j] = (a.carry && f < a.F) ? a.vfeat[(size_t)s * a.F + f] : 0.0f;
     }
-    bool overflow = false;
-
     for (int q = qs; q < qe; ++q) {
         if (!a.carry) {
 #pragma unroll
@@ -201,8 +214,9 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                     if (f < a.F) a.featspk[((size_t)q * a.T + t) * a.F + f] = sp[j];
                 }
             }
+            uint2 *ev2 = reinterpret_cast<uint2 *>(ev);
             if (total == 0) {
-                if (lane == 0) ev[count] = EV_LAST;
+                if (lane == 0) ev2[count] = make_uint2(0u, EV_LAST);
                 count += 1;
             } else {
                 uint32_t base = count;
@@ -210,20 +224,19 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                 for (int j = 0; j < FPL; ++j) {
                     if (sp[j] > 0.0f) {
                         const uint32_t pos = base + lanes_below(sm[j]);
-                        const uint32_t bits = __float_as_uint(sp[j]);
-                        if (bits & 0xffffu) overflow = true;
-                        uint32_t word = (uint32_t)(j * 64 + lane) | (bits & 0xffff0000u);
-                        if (pos == count + total - 1) word |= EV_LAST;
-                        ev[pos] = word;
+                        uint32_t bits = __float_as_uint(sp[j]);
+                        if (pos == count + total - 1) bits |= EV_LAST;
+                        ev2[pos] = make_uint2((uint32_t)(j * 64 + lane) * (uint32_t)a.ev_scale, bits);
                     }
                     base += (uint32_t)__builtin_popcountll(sm[j]);
                 }
                 count += total;
             }
         }
-        const uint32_t pad = (16u - (count & 15u)) & 15u;
-        if ((uint32_t)lane < pad) ev[count + lane] = 0u;
-        if (lane == 0) a.nwords[q] = count + pad;
+        // count is in events (2 words each); pad with null events to a whole 16-word chunk
+        const uint32_t pad = (8u - (count & 7u)) & 7u;
+        if ((uint32_t)lane < pad) reinterpret_cast<uint2 *>(ev)[count + lane] = make_uint2(0u, 0u);
+        if (lane == 0) a.nwords[q] = 2u * (count + pad);
     }
     if (a.carry) {
 #pragma unroll
@@ -232,7 +245,6 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
             if (f < a.F) a.vfeat[(size_t)s * a.F + f] = v[j];
         }
     }
-    if (overflow) atomicOr(a.status, LENS_STATUS_SPIKE_OVERFLOW);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -263,11 +275,93 @@ __device__ __forceinline__ void vec_unpack(const typename VecT<PPL>::type &x, fl
     else { o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; }
 }
 
+// Weight reads for one chunk of the spike stream (8 events), issued together.  They are completed
+// (weights_token) before the NEXT chunk's scalar load is put in flight: LDS and scalar memory share the
+// LGKM counter and scalar loads return out of order, so an LDS wait with a scalar load outstanding would
+// degenerate to lgkmcnt(0) and wait for the prefetch too.
+template <int PPL, bool W_LDS>
+__device__ __forceinline__ void load_weights(const uint32_t (&e)[16], const unsigned char *smem, const float *w2t,
+                                             int ldw, int pl, uint32_t lane_off, float (&w)[8][PPL])
+{
+    using vec_t = typename VecT<PPL>::type;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        vec_t wv;
+        if constexpr (W_LDS) {
+            wv = *reinterpret_cast<const vec_t *>(smem + (e[2 * i] + lane_off));
+        } else {
+            wv = *reinterpret_cast<const vec_t *>(w2t + (size_t)e[2 * i] * ldw + pl);
+        }
+        vec_unpack<PPL>(wv, w[i]);
+    }
+}
+
+// Ordering token without any memory clobber or `volatile` (either would stop the compiler from using
+// scalar loads for the stream): a zero in an SGPR that is *data-dependent* on the weights just read.
+// Adding it to the next chunk's offset makes the next scalar load wait until the LDS reads have
+// completed (the asm needs the weights in registers => lgkmcnt(0) before it).
+template <int PPL>
+__device__ __forceinline__ uint32_t weights_token(const float (&w)[8][PPL])
+{
+    uint32_t t0, t1 = 0;
+    if constexpr (PPL == 1) {
+        asm("s_mov_b32 %0, 0" : "=s"(t0) : "v"(w[0][0]), "v"(w[1][0]), "v"(w[2][0]), "v"(w[3][0]),
+                                           "v"(w[4][0]), "v"(w[5][0]), "v"(w[6][0]), "v"(w[7][0]));
+    } else if constexpr (PPL == 2) {
+        asm("s_mov_b32 %0, 0" : "=s"(t0) : "v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]),
+                                           "v"(w[2][0]), "v"(w[2][1]), "v"(w[3][0]), "v"(w[3][1]),
+                                           "v"(w[4][0]), "v"(w[4][1]), "v"(w[5][0]), "v"(w[5][1]),
+                                           "v"(w[6][0]), "v"(w[6][1]), "v"(w[7][0]), "v"(w[7][1]));
+    } else {
+        asm("s_mov_b32 %0, 0" : "=s"(t0) : "v"(w[0][0]), "v"(w[0][1]), "v"(w[0][2]), "v"(w[0][3]),
+                                           "v"(w[1][0]), "v"(w[1][1]), "v"(w[1][2]), "v"(w[1][3]),
+                                           "v"(w[2][0]), "v"(w[2][1]), "v"(w[2][2]), "v"(w[2][3]),
+                                           "v"(w[3][0]), "v"(w[3][1]), "v"(w[3][2]), "v"(w[3][3]));
+        asm("s_mov_b32 %0, 0" : "=s"(t1) : "v"(w[4][0]), "v"(w[4][1]), "v"(w[4][2]), "v"(w[4][3]),
+                                           "v"(w[5][0]), "v"(w[5][1]), "v"(w[5][2]), "v"(w[5][3]),
+                                           "v"(w[6][0]), "v"(w[6][1]), "v"(w[6][2]), "v"(w[6][3]),
+                                           "v"(w[7][0]), "v"(w[7][1]), "v"(w[7][2]), "v"(w[7][3]));
+    }
+    return t0 | t1;
+}
+
+// The 8 events of a chunk against this lane's PPL places.  All control flow is wave-uniform (the
+// event words live in SGPRs); no memory instruction in here.
+template <int PPL>
+__device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[16], const float (&w)[8][PPL], float (&v)[PPL],
+                                                float (&cnt)[PPL], float (&acc)[PPL])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float sv = __builtin_fabsf(__uint_as_float(e[2 * i + 1]));
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) acc[k] = __builtin_fmaf(sv, w[i][k], acc[k]);
+        if ((int32_t)e[2 * i + 1] < 0) {   // LAST event of the step: integrate-and-fire
+            bool fire = false;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                v[k] = v[k] + acc[k];
+                acc[k] = 0.0f;
+                fire |= (v[k] >= 1.0f);
+            }
+            if (__builtin_amdgcn_ballot_w64(fire) != 0) {   // rare: some lane reaches threshold
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    const float sp = __builtin_floorf(__builtin_fmaxf(v[k], 0.0f));
+                    v[k] -= sp;
+                    cnt[k] += sp;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) v[k] = iaf_clip(v[k]);
+        }
+    }
+}
+
 template <int PPL, bool W_LDS>
 __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using vec_t = typename VecT<PPL>::type;
     constexpr int PT = 64 * PPL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -298,6 +392,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         for (int k = 0; k < PPL; ++k) v[k] = (pl + k < a.P) ? a.vout[(size_t)grp * a.ldv + pl + k] : 0.0f;
     }
     const int qstep = a.carry ? 1 : nw;
+    const uint32_t lane_off = (uint32_t)lane * (PPL * 4);
     for (int q = qs + (a.carry ? 0 : wave); q < qe; q += qstep) {
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
@@ -307,35 +402,28 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         }
         const uint32_t *ev = a.events + (size_t)q * a.cap;
         const int nch = (int)(a.nwords[q] >> 4);
-        for (int c = 0; c < nch; ++c) {
-            uint32_t e[16];
+        // 8 events (16 words) per scalar load, two SGPR buffers in ping-pong.  Per chunk: weight reads ->
+        // lgkmcnt(0) -> scalar load of the next chunk -> VALU/SALU-only integration while it is in flight.
+        uint32_t ea[16], eb[16];
+        float w[8][PPL];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) e[i] = ev[c * 16 + i];
-            float w[16][PPL];
+        for (int i = 0; i < 16; ++i) ea[i] = ev[i];
+        for (int c = 0; c < nch; c += 2) {
+            load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, w);
+            const uint32_t *nxt = ev + (size_t)(c + 1) * 16 + weights_token<PPL>(w);
+            if (c + 1 < nch) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t f = e[i] & EV_FMASK;
-                vec_t wv;
-                if constexpr (W_LDS) {
-                    wv = *reinterpret_cast<const vec_t *>(smem + (size_t)f * (PT * 4) + lane * (PPL * 4));
-                } else {
-                    wv = *reinterpret_cast<const vec_t *>(a.w2t + (size_t)f * a.ldw + pl);
-                }
-                vec_unpack<PPL>(wv, w[i]);
+                for (int i = 0; i < 16; ++i) eb[i] = nxt[i];
             }
+            integrate_chunk<PPL>(ea, w, v, cnt, acc);
+            if (c + 1 >= nch) break;
+            load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
+            nxt = ev + (size_t)(c + 2) * 16 + weights_token<PPL>(w);
+            if (c + 2 < nch) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float sv = __uint_as_float(e[i] & 0xffff0000u);
-#pragma unroll
-                for (int k = 0; k < PPL; ++k) acc[k] = __builtin_fmaf(sv, w[i][k], acc[k]);
-                if (e[i] & EV_LAST) {
-#pragma unroll
-                    for (int k = 0; k < PPL; ++k) {
-                        cnt[k] += iaf_update(v[k], acc[k]);
-                        acc[k] = 0.0f;
-                    }
-                }
+                for (int i = 0; i < 16; ++i) ea[i] = nxt[i];
             }
+            integrate_chunk<PPL>(eb, w, v, cnt, acc);
         }
         float *o = a.counts + (size_t)q * a.ldo + pl;
 #pragma unroll
@@ -579,28 +667,43 @@ int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_co
 
 size_t lens_event_capacity_words(int T, int F)
 {
-    const size_t per_step = (size_t)(F > 1 ? F : 1);
-    return (((size_t)(T > 0 ? T : 0) * per_step) + 15) & ~(size_t)15;
+    const size_t per_step = (size_t)(F > 1 ? F : 1);   // events per step, 2 words each
+    return ((2 * (size_t)(T > 0 ? T : 0) * per_step) + 15) & ~(size_t)15;
+}
+
+// places per lane of the output kernel for a given F: the widest tile whose W2^T columns fit in LDS
+static int output_ppl(int F)
+{
+    for (int c : {4, 2, 1})
+        if ((size_t)F * 64 * c * 4 <= (size_t)LDS_BUDGET - 1024) return c;
+    return 0;
+}
+
+int lens_event_scale(int F)
+{
+    const int ppl = output_ppl(F);
+    return ppl ? 64 * ppl * 4 : 1;
 }
 
 int lens_feature_events(const uint8_t *d_frames, int Q, int HW, const int32_t *d_sel, int N,
                         const uint8_t *d_codes, int T, const float *d_w1t, int F, int ldw1,
                         float *d_vfeat, int n_streams, int carry,
-                        uint32_t *d_events, int cap_words, uint32_t *d_nwords,
-                        float *d_featspk, int32_t *d_status, void *stream)
+                        uint32_t *d_events, int cap_words, uint32_t *d_nwords, int ev_scale,
+                        float *d_featspk, void *stream)
 {
-    if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_events || !d_nwords || !d_status) return LENS_ERR_NULL;
+    if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_events || !d_nwords) return LENS_ERR_NULL;
     if (carry && !d_vfeat) return LENS_ERR_NULL;
     if (Q < 0 || HW <= 0 || N <= 0 || T <= 0 || F <= 0 || ldw1 < F) return LENS_ERR_SIZE;
     if ((size_t)cap_words < lens_event_capacity_words(T, F) || (cap_words & 15)) return LENS_ERR_SIZE;
     if (N > 1024 || F > 2048) return LENS_ERR_UNSUPPORTED;
+    if (ev_scale < 1 || (long long)ev_scale * F > 0x7fffffffLL) return LENS_ERR_SIZE;
     if (Q == 0) return LENS_OK;
     if (n_streams <= 0 || n_streams > Q) {
         if (carry && n_streams > Q) return LENS_ERR_SIZE;
         n_streams = carry ? 1 : Q;
     }
     FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, d_vfeat, n_streams, carry ? 1 : 0,
-               d_events, cap_words, d_nwords, d_featspk, d_status};
+               d_events, cap_words, d_nwords, ev_scale, d_featspk};
     hipStream_t st = (hipStream_t)stream;
     const int npl = (N + 63) / 64;
     if (npl <= 1) return dispatch_feature_f<1>(a, st);
@@ -618,14 +721,10 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     if (carry && !d_vout) return LENS_ERR_NULL;
     if (Q < 0 || F <= 0 || P <= 0 || ldw2 < P || ldo < P || cap_words <= 0 || (carry && ldv < P)) return LENS_ERR_SIZE;
     if ((ldw2 & 255) || ((uintptr_t)d_w2t & 15)) return LENS_ERR_ALIGN;
-    if (F > (int)EV_FMASK) return LENS_ERR_UNSUPPORTED;
     if (Q == 0) return LENS_OK;
     hipStream_t st = (hipStream_t)stream;
 
-    // places per lane: the widest tile whose W2^T columns fit in LDS
-    int ppl = 0;
-    for (int c : {4, 2, 1})
-        if ((size_t)F * 64 * c * 4 <= (size_t)LDS_BUDGET - 1024) { ppl = c; break; }
+    const int ppl = output_ppl(F);
     const int pt = 64 * (ppl ? ppl : 4);
     const int ntiles = (P + pt - 1) / pt;
 

@@ -116,10 +116,10 @@ class LensEngine:
         w2t[:, :self.P] = w2.t().to(dev)
         self.w2t = w2t
         self.cap = int(_lib.lib().lens_event_capacity_words(self.T, self.F))
+        self.ev_scale = int(_lib.lib().lens_event_scale(self.F))
         self.n_streams = 1
         self.reset_state()
         self._ws_q = 0
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
 
     # ---- state -------------------------------------------------------------------------
     def reset_state(self, n_streams=1):
@@ -148,7 +148,7 @@ class LensEngine:
         st = _lib.lib().lens_feature_events(
             _ptr(frames), Q, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
             _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), n_streams, int(carry),
-            _ptr(self.events), self.cap, _ptr(self.nwords), _ptr(spk), _ptr(self.status), _stream())
+            _ptr(self.events), self.cap, _ptr(self.nwords), self.ev_scale, _ptr(spk), _stream())
         _lib.check(st, "lens_feature_events")
         return spk
 
@@ -182,11 +182,8 @@ class LensEngine:
         return out
 
     def check_status(self):
-        s = int(self.status.item())
-        if s & 1:
-            self.status.zero_()
-            raise _lib.LensAmdError("a feature neuron's per-step spike count needs more than 8 significant bits "
-                                    "(>= 257): outside the exact range of the spike-stream encoding")
+        """Kept for API stability: the spike stream now carries full float32 counts, nothing can overflow."""
+        return None
 
     # ---- matching ----------------------------------------------------------------------
     def seqmatch(self, counts, L):

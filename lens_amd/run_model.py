@@ -1,0 +1,164 @@
+"""Inference driver: the host-side mirror of lens/run_model.py for the GPU hot path.
+
+Same public surface as the reference (`LENS(args)`, `.add_layer`, `.load_model`, `.evaluate`,
+`run_inference`, attribute names, model-file keys, log/PDF artefacts, the returned Recall list);
+the numeric core -- raster, both Linear layers, the three sinabs IAF layers, the time-sum, the
+sequence matcher and (for large databases) the top-k -- runs in liblens_amd.so on the GPU.
+
+Semantics kept from the reference, on purpose:
+  * the membrane state is carried from query to query (the reference never calls reset_states(),
+    lens/run_model.py:234-242); `--amd_state reset` selects the per-query-reset variant instead;
+  * Recall@N uses numpy's default argsort on the full matrix, like lens/src/metrics.py:219;
+  * sequence_length == 0 skips the matcher and leaves the matrix untransposed (run_model.py:253-254).
+There is no CPU execution path: without a ROCm GPU (or with --nocuda) construction fails.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import blitnet as bn
+from ._lib import LensAmdError
+from .dataset import CustomImageDataset
+from .loggers import model_logger
+from .metrics import recallAtK
+
+RECALL_N = [1, 5, 10, 15, 20, 25]
+
+
+def format_table(field_names, row):
+    """ASCII table in PrettyTable's default layout (the reference logs a PrettyTable, run_model.py:305-308)."""
+    cells = [[str(x) for x in field_names], [str(x) for x in row]]
+    width = [max(len(c[i]) for c in cells) + 2 for i in range(len(field_names))]
+    rule = "+" + "+".join("-" * w for w in width) + "+"
+    fmt = lambda c: "|" + "|".join(s.center(w) for s, w in zip(c, width)) + "|"
+    return "\n".join([rule, fmt(cells[0]), rule, fmt(cells[1]), rule])
+
+
+def create_GTtol(GT, distance=2):
+    """Ground truth with tolerance: binary dilation with a (2d+1)^2 square (run_model.py:272-289).
+    Host-side scipy, as in the reference."""
+    from scipy.ndimage import binary_dilation
+    return binary_dilation(GT, structure=np.ones((2 * distance + 1, 2 * distance + 1), dtype=int)).astype(int)
+
+
+class LENS(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        for name in vars(args):
+            setattr(self, name, getattr(args, name))
+        self.dataset_file = os.path.join(self.data_dir, self.query + ".csv")
+        self.query_dir = os.path.join(self.data_dir, self.dataset, self.camera, self.query)
+        self.reference_dir = os.path.join(self.data_dir, self.dataset, self.camera, self.reference)
+        self.device = model_logger(self)
+        if getattr(self, "nocuda", False) or self.device.type != "cuda":
+            raise LensAmdError("lens_amd runs the LENS hot path on an MI355X only: no ROCm device is usable "
+                               "(--nocuda was given or none is present) and there is no CPU fallback")
+        self.layer_dict = {}
+        self.layer_counter = 0
+        self.input = int(args.dims * args.dims)
+        self.feature = int(self.input * self.feature_multiplier)
+        self.output = int(args.reference_places)
+        self.add_layer("feature_layer", dims=[self.input, self.feature], device=self.device, inference=True)
+        self.add_layer("output_layer", dims=[self.feature, self.output], device=self.device, inference=True)
+        if not hasattr(self, "matrix"):
+            self.matrix = None
+        self.kernel_size = self.roi_dim // self.dims
+        self.engine = None
+
+    def add_layer(self, name, **kwargs):
+        if name in self.layer_dict:
+            raise ValueError(f"Layer with name {name} already exists.")
+        setattr(self, name, bn.SNNLayer(**kwargs))
+        self.layer_dict[name] = self.layer_counter
+        self.layer_counter += 1
+
+    def load_model(self, model_path):
+        """torch.save(state_dict) files of the reference: keys <layer>.thr, <layer>.w.weight (f32)."""
+        self.load_state_dict(torch.load(model_path, map_location="cpu", weights_only=True), strict=False)
+
+    # ------------------------------------------------------------------------------------
+    def build_engine(self):
+        from .engine import LensEngine
+        self.engine = LensEngine(self.feature_layer.w.weight.detach(), self.output_layer.w.weight.detach(),
+                                 self.roi_dim, self.dims, self.timebin, device=self.device)
+        return self.engine
+
+    def similarity_rows(self, frames):
+        """out[Q,P]: spike counts of the output layer per query (run_model.py:229-246)."""
+        if self.engine is None:
+            self.build_engine()
+        carry = getattr(self, "amd_state", "carry") != "reset"
+        self.engine.reset_state()
+        counts = self.engine.forward_counts(frames.to(self.device), carry=carry)
+        return counts
+
+    def evaluate(self, test_loader, model):
+        """test_loader: a CustomImageDataset (or anything with .frames() -> uint8 [Q,H,W])."""
+        import matplotlib
+        if os.environ.get("DISPLAY", "") == "" and not os.environ.get("MPLBACKEND"):
+            matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        from .engine import seqmatch
+
+        frames = test_loader.frames() if hasattr(test_loader, "frames") else test_loader
+        counts = self.similarity_rows(frames)
+        out = counts.cpu().numpy().astype(np.float64)
+        out = np.reshape(out, (model.query_places, model.reference_places))
+        if self.sequence_length != 0:
+            S_dev = seqmatch(counts, self.sequence_length)              # query-major on the device
+            dist_matrix_seq = np.ascontiguousarray(S_dev.cpu().numpy().T)   # reference orientation
+        else:
+            dist_matrix_seq = out
+        np.save(os.path.join(self.output_folder, "similarity_matrix.npy"), dist_matrix_seq)
+
+        plt.imshow(dist_matrix_seq)
+        plt.colorbar()
+        plt.savefig(os.path.join(self.output_folder, "distance_matrix_lens.pdf"))
+        plt.close()
+
+        R = []
+        if self.matching:
+            GT = np.load(os.path.join(self.data_dir, self.dataset, self.camera,
+                                      self.reference + "_" + self.query + "_GT.npy"))
+            if self.sequence_length != 0:
+                GT = GT[self.sequence_length - 2:-1, self.sequence_length - 2:-1]
+            GTtol = create_GTtol(GT, distance=self.GT_tolerance).T
+            plt.imshow(GTtol)
+            plt.colorbar()
+            plt.savefig(os.path.join(self.output_folder, "GTtol.pdf"))
+            plt.close()
+            for n in RECALL_N:
+                R.append(round(recallAtK(dist_matrix_seq, GTtol, K=n), 2))
+            model.logger.info(format_table(["N"] + [str(n) for n in RECALL_N], ["Recall"] + R))
+
+        if self.sim_mat:
+            plt.figure(figsize=(10, 8))
+            plt.imshow(dist_matrix_seq, aspect="auto", cmap="viridis")
+            plt.colorbar()
+            plt.title("Similarity matrix")
+            plt.xlabel("Query")
+            plt.ylabel("Database")
+            plt.savefig(os.path.join(self.output_folder, "similarity_matrix.pdf"))
+            plt.show()
+            plt.close()
+
+        if self.PR_curve or self.sad:
+            raise NotImplementedError("--PR_curve / --sad are later rows of the build plan (SURVEY.md 8f-2/8f-3)")
+
+        model.logger.info("")
+        model.logger.info("Succesfully completed inferencing using LENS")
+        return R
+
+
+def run_inference(model, model_name):
+    """Load the query set and the pretrained model, run `evaluate` (lens/run_model.py:360-397)."""
+    test_dataset = CustomImageDataset(annotations_file=model.dataset_file, img_dir=model.query_dir,
+                                      kernel_size=model.kernel_size, skip=model.filter,
+                                      max_samples=model.query_places, is_spiking=True,
+                                      time_window=model.timebin)
+    model.eval()
+    model.load_model(os.path.join("./lens/models", model_name))
+    return model.evaluate(test_dataset, model)

@@ -204,7 +204,7 @@ def raster_golden():
                                 img_dir=os.path.join(REF, "lens/dataset", d),
                                 transform=transforms.Compose([ProcessImage()]), kernel_size=k, skip=1,
                                 max_samples=3, is_spiking=True, time_window=T)
-        c0 = k // 2 - 1
+        c0 = (k // 2 - 1) % k          # k == 1: the reference's kernel[-1, -1] is Python negative indexing
         sel = []
         for i in range(3):
             spikes = ds[i][0]                      # [T,1,H,W] float {0,1}
@@ -227,6 +227,8 @@ if __name__ == "__main__":
     os.environ["TQDM_DISABLE"] = "1"
     _install_stubs(CAPTURE)
     raster_golden()
+    if "--raster-only" in sys.argv:
+        sys.exit(0)
     one_config("example", ["--matching", "--nocuda"])
     one_config("sunset", ["--matching", "--nocuda", "--dataset", "brisevent", "--camera", "davis346",
                           "--reference", "sunset2", "--query", "sunset1", "--reference_places", "641",

@@ -135,17 +135,17 @@ def test_empty_and_saturated_frames(O):
     assert out[0].sum() == 0
 
 
-def test_spike_overflow_is_reported():
-    """A per-step spike count with more than 8 significant bits (257) cannot be encoded in the stream:
-    the engine must raise, not return wrong counts."""
-    from lens_amd._lib import LensAmdError
-    dims, roi, T = 2, 2, 4
+def test_large_multi_spike_counts_are_exact(O):
+    """Hundreds of spikes per step (multi-spike) travel through the stream as full float32 counts."""
+    dims, roi, T = 2, 2, 6
     w1 = np.full((3, 4), 64.25, np.float32)      # 4 inputs * 64.25 -> 257 spikes in one step
-    w2 = np.zeros((5, 3), np.float32)
+    w1[1] = 0.3
+    w2 = (np.arange(15, dtype=np.float32).reshape(5, 3) - 7) * 0.013
     eng = _engine(w1, w2, roi, dims, T=T)
-    frames = np.full((1, 2, 2), 255, np.uint8)
-    with pytest.raises(LensAmdError):
-        eng.forward_counts(torch.from_numpy(frames).cuda(), carry=False)
+    frames = np.array([[[255, 255], [255, 255]], [[200, 3], [90, 255]]], np.uint8)
+    out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=True).cpu().numpy()
+    ref = O.forward(frames, dims, O.rand_U(T, 4), w1, w2, carry=True)
+    assert np.array_equal(out, ref) and out.max() > 100
 
 
 def test_topk_ties_and_short_lists(O):

@@ -33,11 +33,12 @@ def gather_topk(idx, val, group=None):
     """All-gather per-shard top-K lists: idx int32 [Q',K], val float32 [Q',K] -> [world,Q',K] each.
     Works with any backend (RCCL on device tensors; gloo on CPU tensors in the tests)."""
     world = dist.get_world_size(group)
-    idx_all = torch.empty((world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
-    val_all = torch.empty((world,) + tuple(val.shape), dtype=val.dtype, device=val.device)
+    q, k = idx.shape
+    idx_all = torch.empty((world * q, k), dtype=idx.dtype, device=idx.device)   # concatenation along dim 0
+    val_all = torch.empty((world * q, k), dtype=val.dtype, device=val.device)
     dist.all_gather_into_tensor(idx_all, idx.contiguous(), group=group)
     dist.all_gather_into_tensor(val_all, val.contiguous(), group=group)
-    return idx_all, val_all
+    return idx_all.view(world, q, k), val_all.view(world, q, k)
 
 
 class ShardedMatcher:

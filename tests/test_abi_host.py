@@ -1,0 +1,208 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the header declares, its host
+helpers and argument checks work, and the host-side logic (pixel selection, threshold codes, CLI
+surface, sharding arithmetic) matches the reference behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, GOLDEN, load_config
+
+
+@pytest.fixture(scope="module")
+def L():
+    from lens_amd import _lib
+    _lib.build()
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    from lens_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "lens_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lens_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    raw = ctypes.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert L.lens_amd_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
+    assert L.lens_feature_events(None, 1, 1, None, 1, None, 1, None, 1, 1, None, 1, 0, None, 16, None, 1, None, None) == -1
+    assert L.lens_output_counts(None, 16, None, 1, None, 1, 1, 256, None, 1, 1, 0, None, 1, None) == -1
+    assert L.lens_seqmatch_topk(None, 1, 1, 1, 1, 1, 0, None, None, None) == -1
+    assert L.lens_accumulate_events(None, None, 0, 8, None, None, None) == -1
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.lens_accumulate_events(p, p, 1, 500, p, p, None) == -3          # roi too large for the LDS histogram
+    assert L.lens_seqmatch_topk(p, 4, 8, 4, 2, 65, 0, p, p, None) == -2       # K > 64
+    assert L.lens_seqmatch_topk(p, 1, 8, 4, 2, 5, 0, p, p, None) == -2        # fewer queries than L
+    assert L.lens_output_counts(p, 16, p, 1, p, 4, 10, 100, None, 10, 1, 0, p, 10, None) == -4   # ldw2 % 256
+    assert L.lens_amd_strerror(-2).decode().startswith("a size")
+    assert L.lens_event_capacity_words(250, 200) == 100000
+    assert L.lens_event_capacity_words(3, 0) == 16
+    assert L.lens_event_scale(200) == 512 and L.lens_event_scale(63) == 1024 and L.lens_event_scale(5000) == 1
+
+
+def test_product_refuses_to_run_without_gpu():
+    """No CPU fallback: engine construction and device ops raise when there is no ROCm device."""
+    from lens_amd._lib import LensAmdError
+    from lens_amd.engine import LensEngine, seqmatch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(LensAmdError):
+        LensEngine(np.zeros((4, 4), np.float32), np.zeros((3, 4), np.float32), 2, 2, 5, device="cpu")
+    with pytest.raises(LensAmdError):
+        seqmatch(torch.zeros(4, 4), 2)
+
+
+@pytest.mark.parametrize("roi,dims", [(80, 10), (128, 10), (7, 7), (36, 12), (9, 4)])
+def test_centre_pixel_index_is_the_reference_conv(roi, dims):
+    """sel[n] picks exactly the pixel the one-hot Conv2d of lens/run_model.py:130-137 selects."""
+    from lens_amd.engine import centre_pixel_index
+    k = roi // dims
+    conv = torch.nn.Conv2d(1, 1, kernel_size=k, stride=k, padding=0, bias=False)
+    w = torch.zeros(1, 1, k, k)
+    c = (k // 2) - 1
+    w[0, 0, c, c] = 1
+    conv.weight = torch.nn.Parameter(w, requires_grad=False)
+    img = torch.arange(roi * roi, dtype=torch.float32).reshape(1, 1, roi, roi)
+    want = conv(img)[0, 0, :dims, :dims].reshape(-1).numpy().astype(np.int64)
+    assert np.array_equal(centre_pixel_index(roi, dims), want[:dims * dims])
+
+
+@pytest.mark.parametrize("T,roi,dims", [(250, 80, 10), (250, 7, 7), (40, 128, 10)])
+def test_threshold_codes_reproduce_the_float_raster(T, roi, dims, L):
+    """(px >= code)  <=>  (U < px/255 in float32) for every one of the 256 pixel values."""
+    from lens_amd.engine import build_threshold_codes, centre_pixel_index, rand_tensor
+    sel = centre_pixel_index(roi, dims)
+    codes = build_threshold_codes(T, roi, sel).numpy()
+    U = rand_tensor(T, roi * roi)[:, torch.as_tensor(sel, dtype=torch.long)]
+    assert codes.min() >= 1
+    for px in range(256):
+        img = (torch.tensor([px], dtype=torch.uint8) / 255)            # dataset.py:23
+        want = (U < img).numpy()
+        assert np.array_equal(codes <= px, want), px
+
+
+def test_rand_tensor_matches_golden_fingerprint():
+    import hashlib
+    from lens_amd.engine import rand_tensor
+    R = np.load(os.path.join(GOLDEN, "raster.npz"))
+    U = rand_tensor(250, 6400).numpy()
+    assert hashlib.sha256(U.tobytes()).digest() == R["U_250_6400_sha256"].tobytes()
+
+
+def test_cli_surface_matches_the_reference():
+    """44 reference flags with their defaults (main.py:85-186) + model-name rule (main.py:27-38)."""
+    import main
+    p = main.build_parser()
+    a = p.parse_args([])
+    ref_defaults = dict(dataset="example", camera="davis128", data_name="experiment001", reference="example-reference",
+                        query="example-query", data_dir="./lens/dataset/", reference_places=100, query_places=100,
+                        sequence_length=2, feature_multiplier=2.0, filter=1, epoch_feat=128, epoch_out=128,
+                        thr_l_feat=0, thr_h_feat=0.75, fire_l_feat=0.4, fire_h_feat=0.6, ip_rate_feat=0.02,
+                        stdp_rate_feat=0.01, thr_l_out=0, thr_h_out=0.5, fire_l_out=0.5, fire_h_out=0.5,
+                        ip_rate_out=0.02, stdp_rate_out=0.01, f_exc=0.35, f_inh=0.75, o_exc=1.0, o_inh=1.0, dims=10,
+                        roi_dim=80, train_model=False, GT_tolerance=3, sim_mat=False, PR_curve=False, matching=False,
+                        sad=False, timebin=250, nocuda=False, event_driven=False, simulated_speck=False,
+                        collect_data=False, headless=False, save_input=False)
+    assert len(ref_defaults) == 44
+    for k, v in ref_defaults.items():
+        assert getattr(a, k) == v, k
+
+    class M:
+        reference = "sunset2"; input = 49; feature = 63; reference_places = 641
+    assert main.generate_model_name(M) == "sunset2_LENS_IN49_FN63_DB641.pth"
+    assert os.path.exists(os.path.join(ROOT, "lens", "models", main.generate_model_name(M)))
+
+
+def test_checker_assertions(tmp_path):
+    import main
+    from lens_amd import checker
+    a = main.build_parser().parse_args([])
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        checker.check_args(a)
+        bad = main.build_parser().parse_args(["--dims", "9", "--roi_dim", "80"])    # 80//9 = 8 -> conv gives 10, not 9
+        with pytest.raises(AssertionError, match="ROI dimension"):
+            checker.check_args(bad)
+        bad = main.build_parser().parse_args(["--query_places", "101"])
+        with pytest.raises(AssertionError, match="Not enough query images"):
+            checker.check_args(bad)
+        bad = main.build_parser().parse_args(["--dataset", "nope"])
+        with pytest.raises(AssertionError, match="Data directory does not exist"):
+            checker.check_args(bad)
+    finally:
+        os.chdir(cwd)
+
+
+def test_model_file_loads_into_the_mirror_container():
+    """The reference's state_dict keys load bit-exactly into blitnet.SNNLayer containers."""
+    from lens_amd.blitnet import SNNLayer
+    sd = torch.load(os.path.join(ROOT, "lens", "models", "example-reference_LENS_IN100_FN200_DB100.pth"),
+                    map_location="cpu", weights_only=True)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.feature_layer = SNNLayer(dims=[100, 200], inference=True)
+            self.output_layer = SNNLayer(dims=[200, 100], inference=True)
+    net = Net()
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert torch.equal(net.feature_layer.w.weight, sd["feature_layer.w.weight"])
+    assert net.output_layer.thr.shape == (1, 100)
+
+
+def test_dataset_loader_and_metrics_mirror():
+    from lens_amd.dataset import CustomImageDataset
+    from lens_amd.metrics import recallAtK, recall_from_topk
+    from oracle import oracle as O
+    c, frames, w1, w2, gt, G = load_config("example")
+    ds = CustomImageDataset(os.path.join(ROOT, "lens/dataset/example-query.csv"),
+                            os.path.join(ROOT, "lens/dataset/example/davis128/example-query"), skip=3, max_samples=7)
+    assert len(ds) == 7 and np.array_equal(ds.frames().numpy(), frames[::3][:7])
+    assert ds[2][1] == 6
+    with pytest.raises(FileNotFoundError):
+        CustomImageDataset(os.path.join(ROOT, "lens/dataset/example-query.csv"), "/nonexistent")[0]
+    GT = G["GTtol"]
+    S = G["S_carry"]
+    R = [recallAtK(S, GT, K=k) for k in (1, 5, 10, 15, 20, 25)]
+    assert np.allclose(R, G["recall_carry"], rtol=0, atol=0)           # same numbers as lens/src/metrics.py
+    idx, _ = O.topk(S, 25)
+    for k in (1, 5, 25):
+        assert recall_from_topk(idx, GT, k) == recallAtK(S, GT, K=k, sort_kind="stable")
+    with pytest.raises(AssertionError):
+        recallAtK(S, GT[:-1], K=1)
+
+
+def test_table_format_and_shard_bounds():
+    from lens_amd.run_model import format_table
+    from lens_amd.dist import shard_bounds, shard_rows
+    t = format_table(["N", "1", "5"], ["Recall", 0.63, 0.84]).splitlines()
+    assert t[0] == "+--------+------+------+" and t[1] == "|   N    |  1   |  5   |" and t[3] == "| Recall | 0.63 | 0.84 |"
+    for P, Lq, W in ((100000, 2, 8), (1000, 2, 3), (641, 3, 5), (10, 1, 4)):
+        b = shard_bounds(P, Lq, W)
+        assert b[0] == 0 and b[-1] == P - Lq + 1 and all(b[i] <= b[i + 1] for i in range(W))
+        rows = [shard_rows(P, Lq, r, W) for r in range(W)]
+        assert rows[-1][1] == P and sum(r[2] for r in rows) == P - Lq + 1
+        assert all(r[1] - r[0] == r[2] + Lq - 1 for r in rows)
+
+
+def test_synthetic_generators_are_deterministic():
+    from lens_amd.synthetic import synthetic_frames, synthetic_database, synthetic_events
+    a, b = synthetic_frames(3, 32, seed=5), synthetic_frames(3, 32, seed=5)
+    assert torch.equal(a, b) and a.dtype == torch.uint8
+    xy, off = synthetic_events(a)
+    from oracle import oracle as O
+    assert np.array_equal(O.accumulate_events(xy[:, 0].numpy(), xy[:, 1].numpy(), off.numpy(), 32), a.numpy())
+    w = torch.randn(10, 6)
+    db = synthetic_database(w, 25)
+    assert db.shape == (25, 6) and torch.equal(db, synthetic_database(w, 25))

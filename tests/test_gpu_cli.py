@@ -1,0 +1,57 @@
+"""GPU end-to-end test of the drop-in surface: `python main.py --matching` (config 1 inputs) must
+reproduce the reference run's similarity matrix and Recall@N table (tests/golden)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SUNSET = ["--dataset", "brisevent", "--camera", "davis346", "--reference", "sunset2", "--query", "sunset1",
+          "--reference_places", "641", "--query_places", "724", "--dims", "7", "--roi_dim", "7",
+          "--feature_multiplier", "1.3"]
+
+
+def _run(argv):
+    import main
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        before = set(glob.glob("lens/output/*"))
+        R = main.parse_network(argv)
+        new = sorted(set(glob.glob("lens/output/*")) - before)
+        assert len(new) == 1
+        return R, os.path.join(ROOT, new[0])
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.parametrize("tag,argv", [("example", []), ("sunset", SUNSET)])
+def test_cli_matching_reproduces_reference_run(tag, argv):
+    G = np.load(os.path.join(GOLDEN, f"{tag}.npz"))
+    R, folder = _run(["--matching"] + argv)
+    assert R == [round(float(x), 2) for x in G["recall_carry"]]
+    S = np.load(os.path.join(folder, "similarity_matrix.npy"))
+    assert S.dtype == np.float32 and np.array_equal(S, G["S_carry"])
+    for f in ("lens.log", "distance_matrix_lens.pdf", "GTtol.pdf"):
+        assert os.path.exists(os.path.join(folder, f))
+    log = open(os.path.join(folder, "lens.log")).read()
+    assert "Recall" in log and "Succesfully completed inferencing using LENS" in log
+
+
+def test_cli_reset_state_variant():
+    G = np.load(os.path.join(GOLDEN, "example.npz"))
+    R, folder = _run(["--matching", "--amd_state", "reset"])
+    assert R == [round(float(x), 2) for x in G["recall_reset"]]
+    assert np.array_equal(np.load(os.path.join(folder, "similarity_matrix.npy")), G["S_reset"])
+
+
+def test_cli_refuses_cpu_and_hw_modes():
+    from lens_amd._lib import LensAmdError
+    with pytest.raises(LensAmdError):
+        _run(["--matching", "--nocuda"])
+    with pytest.raises(SystemExit):
+        _run(["--event_driven"])

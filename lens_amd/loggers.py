@@ -18,7 +18,16 @@ def model_logger(model):
     base = "./lens/output/"
     model.output_folder = base + datetime.now().strftime("%d%m%y-%H-%M-%S")
     os.makedirs(base, exist_ok=True)
-    os.mkdir(model.output_folder)                      # same 1-second granularity as the reference
+    # The reference's folder name has 1-second granularity and a second run within the same second
+    # dies in os.mkdir (loggers.py:13,19); on a GPU two runs per second are normal, so a suffix is added.
+    stem, n = model.output_folder, 1
+    while True:
+        try:
+            os.mkdir(model.output_folder)
+            break
+        except FileExistsError:
+            n += 1
+            model.output_folder = f"{stem}_{n}"
     model.logger = logging.getLogger("LENS")
     if model.logger.hasHandlers():
         model.logger.handlers.clear()

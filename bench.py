@@ -72,6 +72,33 @@ def cpu_baseline(frames, w1, w2, target_cpu_seconds=15.0):
                       f"oracle/lens_oracle.c dense path, one thread per core"}
 
 
+def other_kernel_rooflines(frames_cpu, dev, avg_ms, byts):
+    """HBM rooflines of the memory-bound rows of the path, measured once outside the timed region:
+    a1 event accumulation (4 B/event in + H*W B/frame out) and the in-step seq-match/top-k kernel."""
+    from lens_amd.engine import accumulate_events
+    from lens_amd.synthetic import synthetic_events
+    nf = min(2048, frames_cpu.shape[0])      # ~100 M events = 400 MB: larger than the 256 MB Infinity Cache
+    xy, off = synthetic_events(frames_cpu[:nf])
+    xy, off = xy.to(dev), off.to(dev)
+    accumulate_events(xy, off, ROI)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        fr, bad = accumulate_events(xy, off, ROI, check=False)
+    e1.record(); torch.cuda.synchronize()
+    assert torch.equal(fr.cpu(), frames_cpu[:nf]) and int(bad.item()) == (1 << 63) - 1
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 4.0 * xy.shape[0] + nf * ROI * ROI
+    res = {"k_accumulate_events": {"bound": "hbm", "frames": nf, "events": int(xy.shape[0]), "avg_launch_ms": ms,
+                                   "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    ach = byts[2] / (avg_ms[2] * 1e-3) / 1e9
+    res["k_seqmatch_topk"] = {"bound": "hbm", "avg_launch_ms": avg_ms[2], "achieved": ach, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    return res
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,6 +218,7 @@ def main():
             "kernels_ms": dict(zip(names, avg_ms)),
             "roofline": roof,
         }
+        line["other_kernels"] = other_kernel_rooflines(frames_cpu, dev, avg_ms, byts)
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(frames_cpu, w1, w2 if shard == "queries" else w2)
         print(json.dumps(line))

@@ -59,9 +59,10 @@ __device__ __forceinline__ float iaf_clip(float vm)
 }
 
 // ------------------------------------------------------------------------------------------
-// a1. events -> frames.  One workgroup per frame, uint32 histogram in LDS.
+// a1. events -> frames.  One 16-wave workgroup per frame, uint32 histogram in LDS (64 KB at 128x128:
+// two workgroups = 32 waves per CU), 4 events (16 B) per lane per load.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_accumulate_events(const int16_t *__restrict__ xy,
+__global__ void __launch_bounds__(1024) k_accumulate_events(const int16_t *__restrict__ xy,
                                                            const int64_t *__restrict__ frame_off, int roi,
                                                            uint8_t *__restrict__ frames,
                                                            unsigned long long *__restrict__ first_bad)
@@ -74,18 +75,41 @@ __global__ void __launch_bounds__(256) k_accumulate_events(const int16_t *__rest
     __syncthreads();
     const int64_t e0 = frame_off[fr], e1 = frame_off[fr + 1];
     const uint32_t *ev = reinterpret_cast<const uint32_t *>(xy);
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const uint32_t w = __builtin_nontemporal_load(ev + e);
+    unsigned long long my_bad = ~0ull;   // smallest out-of-range event seen by this thread
+    auto add_event = [&](uint32_t w, int64_t e) {
         int c = (int)(int16_t)(w & 0xffffu) - 1;   // x - 1
         int r = (int)(int16_t)(w >> 16) - 1;       // y - 1
-        if (r < -roi || r >= roi || c < -roi || c >= roi) {
-            atomicMin(first_bad, (unsigned long long)e);
-            continue;
+        const bool ok = (r >= -roi) & (r < roi) & (c >= -roi) & (c < roi);
+        r += (r < 0) ? roi : 0;                    // Python-style negative index
+        c += (c < 0) ? roi : 0;
+        if (ok) atomicAdd(&bins[r * roi + c], 1u);
+        else if ((unsigned long long)e < my_bad) my_bad = (unsigned long long)e;
+    };
+    // head up to a 16-byte boundary, body as 4 events (16 B) per lane with 4 loads in flight, tail
+    int64_t ea = (e0 + 3) & ~(int64_t)3;
+    if (ea > e1) ea = e1;
+    const int64_t eb = ea + ((e1 - ea) & ~(int64_t)3);
+    for (int64_t e = e0 + threadIdx.x; e < ea; e += blockDim.x) add_event(ev[e], e);
+    const uint4 *ev4 = reinterpret_cast<const uint4 *>(ev + ea);
+    const int64_t n4 = (eb - ea) >> 2;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * (int64_t)blockDim.x < n4; i += 4 * (int64_t)blockDim.x) {
+        uint4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = ev4[i + u * (int64_t)blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t e = ea + 4 * (i + u * (int64_t)blockDim.x);
+            add_event(w[u].x, e); add_event(w[u].y, e + 1); add_event(w[u].z, e + 2); add_event(w[u].w, e + 3);
         }
-        if (r < 0) r += roi;
-        if (c < 0) c += roi;
-        atomicAdd(&bins[r * roi + c], 1u);
     }
+    for (; i < n4; i += blockDim.x) {
+        const uint4 w = ev4[i];
+        const int64_t e = ea + 4 * i;
+        add_event(w.x, e); add_event(w.y, e + 1); add_event(w.z, e + 2); add_event(w.w, e + 3);
+    }
+    for (int64_t e = eb + threadIdx.x; e < e1; e += blockDim.x) add_event(ev[e], e);
+    if (my_bad != ~0ull) atomicMin(first_bad, my_bad);
     __syncthreads();
     uint8_t *out = frames + (size_t)fr * nb;
     if ((nb & 3) == 0) {
@@ -489,23 +513,32 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
     float tn = -1.0f;   // current K-th best
     int tj = -1;
     const int nchunks = (n_places + 63) >> 6;
-    for (int c = wave; c < nchunks; c += nw) {
-        const int j = n_places - 1 - (c * 64 + lane);
-        float n = -2.0f;
-        if (j >= 0) {
-            n = 0.0f;
-            for (int d = 0; d < L; ++d) n += counts[(size_t)(i + d) * ldo + j + d];
+    constexpr int U = 8;   // chunks (loads) in flight per wavefront: the scan is HBM-bound, not latency-bound
+    for (int c0 = wave; c0 < nchunks; c0 += nw * U) {
+        float n[U];
+        int j[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nw;
+            j[u] = (c < nchunks) ? n_places - 1 - (c * 64 + lane) : -1;
+            n[u] = 0.0f;
+            if (j[u] >= 0) {
+                for (int d = 0; d < L; ++d) n[u] += counts[(size_t)(i + d) * ldo + j[u] + d];
+            }
         }
-        uint64_t m = __ballot(j >= 0 && beats(n, j, tn, tj));
-        while (m) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            const float cn = __shfl(n, b);
-            const int cj = __shfl(j, b);
-            if (beats(cn, cj, tn, tj)) {
-                wave_insert(ln, lj, cn, cj, lane);
-                tn = __shfl(ln, K - 1);
-                tj = __shfl(lj, K - 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint64_t m = __ballot(j[u] >= 0 && beats(n[u], j[u], tn, tj));
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const float cn = __shfl(n[u], b);
+                const int cj = __shfl(j[u], b);
+                if (beats(cn, cj, tn, tj)) {
+                    wave_insert(ln, lj, cn, cj, lane);
+                    tn = __shfl(ln, K - 1);
+                    tj = __shfl(lj, K - 1);
+                }
             }
         }
     }
@@ -642,7 +675,7 @@ int lens_accumulate_events(const int16_t *d_xy, const int64_t *d_frame_off, int 
     if ((uintptr_t)d_xy & 3) return LENS_ERR_ALIGN;
     const size_t lds = (size_t)roi * roi * 4;
     if (int e = set_lds(k_accumulate_events, lds)) return e;
-    hipLaunchKernelGGL(k_accumulate_events, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, d_xy, d_frame_off,
+    hipLaunchKernelGGL(k_accumulate_events, dim3(n_frames), dim3(1024), lds, (hipStream_t)stream, d_xy, d_frame_off,
                        roi, d_frames, reinterpret_cast<unsigned long long *>(d_first_bad));
     return (int)hipGetLastError();
 }

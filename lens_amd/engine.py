@@ -30,9 +30,10 @@ def _need_cuda(t, name):
 # --------------------------------------------------------------------------------------------
 # a1: events -> frames                                   (lens/collect_data.py:193-199)
 # --------------------------------------------------------------------------------------------
-def accumulate_events(xy, frame_off, roi):
+def accumulate_events(xy, frame_off, roi, check=True):
     """xy int16 [n_events,2] (x,y 1-based), frame_off int64 [n_frames+1] -> uint8 [n_frames,roi,roi].
-    Raises IndexError where torch indexing in the reference would."""
+    Raises IndexError where torch indexing in the reference would (check=True synchronises to read the
+    flag; check=False returns (frames, first_bad_tensor) without synchronising)."""
     _need_cuda(xy, "xy"); _need_cuda(frame_off, "frame_off")
     assert xy.dtype == torch.int16 and xy.dim() == 2 and xy.shape[1] == 2 and xy.is_contiguous()
     assert frame_off.dtype == torch.int64 and frame_off.is_contiguous()
@@ -41,6 +42,8 @@ def accumulate_events(xy, frame_off, roi):
     bad = torch.full((1,), INT64_MAX, dtype=torch.int64, device=xy.device)
     st = _lib.lib().lens_accumulate_events(_ptr(xy), _ptr(frame_off), n_frames, roi, _ptr(frames), _ptr(bad), _stream())
     _lib.check(st, "lens_accumulate_events")
+    if not check:
+        return frames, bad
     b = int(bad.item())
     if b != INT64_MAX:
         x, y = (int(v) for v in xy[b].tolist())

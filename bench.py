@@ -182,7 +182,7 @@ def main():
         # algorithmic work per launch (DESIGN.md "Measurement"): dense-equivalent FLOPs of the Linear layers
         flops = [2.0 * T_STEPS * eng.N * eng.F * Q, 2.0 * T_STEPS * eng.F * P_local * Q, None]
         # algorithmic bytes per launch for the memory-side kernels
-        byts = [Q * (ROI * ROI + 4.0 * words), None, Q * (SEQ_L * 4.0 * P_local + 8.0 * TOPK)]
+        byts = [Q * (ROI * ROI + 4.0 * words), None, Q * (4.0 * P_local + 8.0 * TOPK)]   # counts are read once from HBM
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):

@@ -484,13 +484,23 @@ __device__ __forceinline__ bool beats(float n1, int j1, float n2, int j2)
     return n1 > n2 || (n1 == n2 && j1 > j2);
 }
 
+// value of lane (l - 1), by DPP wave_shr:1 (no LDS crossbar traffic); lane 0 keeps its own value
+__device__ __forceinline__ int lane_above(int x)
+{
+    return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// wave-uniform lane index -> v_readlane_b32
+__device__ __forceinline__ float bcast(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ int bcast(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+
 __device__ __forceinline__ void wave_insert(float &ln, int &lj, float cn, int cj, int lane)
 {
     const uint64_t m = __ballot(beats(cn, cj, ln, lj));   // the beaten entries form a suffix
     if (m == 0) return;
     const int pos = __builtin_ctzll(m);
-    const float un = __shfl_up(ln, 1);
-    const int uj = __shfl_up(lj, 1);
+    const float un = __int_as_float(lane_above(__float_as_int(ln)));
+    const int uj = lane_above(lj);
     if (lane > pos) { ln = un; lj = uj; }
     else if (lane == pos) { ln = cn; lj = cj; }
 }
@@ -498,12 +508,15 @@ __device__ __forceinline__ void wave_insert(float &ln, int &lj, float cn, int cj
 // a7 + top-K.  One workgroup per query column; wavefronts scan 64-place chunks from the highest
 // place index down (so that later ties never displace earlier ones), keep a private top-64 and
 // merge through LDS.
+// LT = compile-time sequence length (0: use the run-time L), so that the L loads of a chunk are independent.
+template <int LT>
 __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__ counts, int ldo, int n_places,
-                                                       int L, int K, int place_offset,
+                                                       int Lrt, int K, int place_offset,
                                                        int32_t *__restrict__ tk_idx, float *__restrict__ tk_val)
 {
     __shared__ float s_n[4][64];
     __shared__ int s_j[4][64];
+    const int L = LT ? LT : Lrt;
     const int i = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -521,9 +534,13 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
         for (int u = 0; u < U; ++u) {
             const int c = c0 + u * nw;
             j[u] = (c < nchunks) ? n_places - 1 - (c * 64 + lane) : -1;
+            const int jc = j[u] < 0 ? 0 : j[u];   // unconditional loads (clamped index), masked by j[u] below
             n[u] = 0.0f;
-            if (j[u] >= 0) {
-                for (int d = 0; d < L; ++d) n[u] += counts[(size_t)(i + d) * ldo + j[u] + d];
+            if constexpr (LT > 0) {
+#pragma unroll
+                for (int d = 0; d < LT; ++d) n[u] += counts[(size_t)(i + d) * ldo + jc + d];
+            } else {
+                for (int d = 0; d < L; ++d) n[u] += counts[(size_t)(i + d) * ldo + jc + d];
             }
         }
 #pragma unroll
@@ -532,12 +549,12 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
-                const float cn = __shfl(n[u], b);
-                const int cj = __shfl(j[u], b);
+                const float cn = bcast(n[u], b);
+                const int cj = bcast(j[u], b);
                 if (beats(cn, cj, tn, tj)) {
                     wave_insert(ln, lj, cn, cj, lane);
-                    tn = __shfl(ln, K - 1);
-                    tj = __shfl(lj, K - 1);
+                    tn = bcast(ln, K - 1);
+                    tj = bcast(lj, K - 1);
                 }
             }
         }
@@ -553,8 +570,8 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
             if (cj < 0) break;
             if (beats(cn, cj, tn, tj)) {
                 wave_insert(ln, lj, cn, cj, lane);
-                tn = __shfl(ln, K - 1);
-                tj = __shfl(lj, K - 1);
+                tn = bcast(ln, K - 1);
+                tj = bcast(lj, K - 1);
             }
         }
     }
@@ -803,8 +820,15 @@ int lens_seqmatch_topk(const float *d_counts, int Q, int ldo, int n_places, int 
 {
     if (!d_counts || !d_topk_idx || !d_topk_val) return LENS_ERR_NULL;
     if (L < 1 || Q < L || n_places < 1 || n_places + L - 1 > ldo || K < 1 || K > 64) return LENS_ERR_SIZE;
-    hipLaunchKernelGGL(k_seqmatch_topk, dim3(Q - L + 1), dim3(256), 0, (hipStream_t)stream, d_counts, ldo, n_places,
-                       L, K, place_offset, d_topk_idx, d_topk_val);
+    const dim3 grid(Q - L + 1), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (L) {
+    case 1: hipLaunchKernelGGL(k_seqmatch_topk<1>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
+    case 2: hipLaunchKernelGGL(k_seqmatch_topk<2>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
+    case 3: hipLaunchKernelGGL(k_seqmatch_topk<3>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
+    case 4: hipLaunchKernelGGL(k_seqmatch_topk<4>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
+    default: hipLaunchKernelGGL(k_seqmatch_topk<0>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
+    }
     return (int)hipGetLastError();
 }
 

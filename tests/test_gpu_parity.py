@@ -153,7 +153,7 @@ def test_topk_ties_and_short_lists(O):
     from lens_amd.engine import seqmatch_topk
     rng = np.random.default_rng(11)
     out = rng.integers(0, 3, size=(9, 700)).astype(np.float32)
-    for L in (1, 2, 3):
+    for L in (1, 2, 3, 5):
         S = O.seqmatch(out, L)
         for K in (1, 25, 64):
             idx, val = seqmatch_topk(torch.from_numpy(out).cuda(), L, K)

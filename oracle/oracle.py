@@ -46,6 +46,10 @@ def lib():
         L.lens_oracle_seqmatch.argtypes = [c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p]
         L.lens_oracle_topk.restype = None
         L.lens_oracle_topk.argtypes = [c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p, c_p]
+        L.lens_oracle_layer_forward_clamped.restype = None
+        L.lens_oracle_layer_forward_clamped.argtypes = [c_p, c_p, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p]
+        L.lens_oracle_train_layer.restype = None
+        L.lens_oracle_train_layer.argtypes = [c_p] * 12 + [ctypes.c_int] * 4
         _LIB = L
     return _LIB
 
@@ -189,3 +193,52 @@ def load_frames(csv_path, img_dir, skip=1, max_samples=None):
         assert im.ndim == 2 and im.dtype == np.uint8
         frames.append(im)
     return np.stack(frames)
+
+
+# --------------------------------------------------------------------------------------------
+# training path (pinned by tests/golden/train_example.npz, made with the reference's own code)
+# --------------------------------------------------------------------------------------------
+def layer_forward_clamped(x_table, w, thr):
+    """clamp(w(x) - thr, 0, 1) for every sample (lens/train_model.py:163-168)."""
+    x = np.ascontiguousarray(x_table, np.float32); w = np.ascontiguousarray(w, np.float32)
+    thr = np.ascontiguousarray(thr, np.float32).reshape(-1)
+    S, n_in = x.shape; n_out = w.shape[0]
+    y = np.zeros((S, n_out), np.float32)
+    lib().lens_oracle_layer_forward_clamped(_p(x), _p(w), _p(thr), S, n_in, n_out, _p(y))
+    return y
+
+
+def anneal_schedule(eta_ip0, eta_stdp0, T):
+    """Learning rates in effect at each of the T steps of train_layer (lens/train_model.py:150-152,
+    120-128, 179-181): the constructor values at step 0, then every 10 steps
+    eta = init * ((T - mod)/T)**2 with init_itp = 2*eta_stdp0 (torch.mul of a float32 tensor with a
+    Python float)."""
+    import torch
+    eip, est = torch.tensor(eta_ip0, dtype=torch.float32), torch.tensor(eta_stdp0, dtype=torch.float32)
+    init_itp, init_stdp = est * 2, est.clone()
+    out_ip, out_st = np.zeros(T, np.float32), np.zeros(T, np.float32)
+    for mod in range(T):
+        out_ip[mod], out_st[mod] = float(eip), float(est)
+        if mod % 10 == 0:
+            pt = pow(float(T - mod) / T, 2)
+            eip, est = torch.mul(init_itp, pt), torch.mul(init_stdp, pt)
+    return out_ip, out_st
+
+
+def train_layer(w, thr, exc, inh, fire_rate, x_table, order, eta_ip, eta_stdp, force_idx=None, prev_fire_rate=None):
+    """T = len(order) training steps in place on (w, thr). Returns (w, thr)."""
+    w = np.ascontiguousarray(w, np.float32).copy(); thr = np.ascontiguousarray(thr, np.float32).reshape(-1).copy()
+    exc = np.ascontiguousarray(exc, np.uint8); inh = np.ascontiguousarray(inh, np.uint8)
+    fr = np.ascontiguousarray(fire_rate, np.float32).reshape(-1)
+    x = np.ascontiguousarray(x_table, np.float32)
+    order = np.ascontiguousarray(order, np.int32).reshape(-1)
+    eip = np.ascontiguousarray(eta_ip, np.float32); est = np.ascontiguousarray(eta_stdp, np.float32)
+    n_out, n_in = w.shape
+    spk = force_idx is not None
+    fi = np.ascontiguousarray(force_idx, np.int32).reshape(-1) if spk else None
+    pfr = np.ascontiguousarray(prev_fire_rate, np.float32).reshape(-1) if spk else None
+    have_rate = int(fr[0] > 0)
+    lib().lens_oracle_train_layer(_p(w), _p(thr), _p(exc), _p(inh), _p(fr), have_rate, _p(x), _p(order),
+                                  _p(fi) if spk else None, _p(pfr) if spk else None, _p(eip), _p(est),
+                                  n_out, n_in, len(order), int(spk))
+    return w, thr

@@ -132,3 +132,49 @@ def test_accumulate_events_follows_torch_indexing():
         O.accumulate_events(np.array([roi + 1], np.int16), np.array([1], np.int16), np.array([0, 1]), roi)
     with pytest.raises(IndexError):
         torch.zeros((roi, roi), dtype=int)[0, roi]
+
+
+# ---------------------------------------------------------------------------------------------
+# training path: goldens come from the reference's own lens/train_model.py + blitnet.py
+# ---------------------------------------------------------------------------------------------
+def _train_replay(G, upto=None):
+    """Replay the golden run with the oracle; yields (layer, step, w, thr) at the golden snapshot steps."""
+    X, labels = G["x_table"], G["labels"]
+    table = X
+    for lname, spk in (("feature_layer", False), ("output_layer", True)):
+        order = G[f"{lname}_order"].reshape(-1)
+        T = len(order)
+        eip, est = O.anneal_schedule(float(G[f"{lname}_eta0"][0]), float(G[f"{lname}_eta0"][1]), T)
+        assert np.array_equal(np.stack([eip, est], 1), G[f"{lname}_eta_used"])     # annealing schedule restated exactly
+        w, thr = G[f"{lname}_w0"], G[f"{lname}_thr0"]
+        done = 0
+        for k in (1, 2, 10, 11, 37, T):
+            kw = dict(force_idx=labels[order[done:k]], prev_fire_rate=G["feature_layer_fire_rate"]) if spk else {}
+            w, thr = O.train_layer(w, thr, G[f"{lname}_exc"], G[f"{lname}_inh"], G[f"{lname}_fire_rate"], table,
+                                   order[done:k], eip[done:k], est[done:k], **kw)
+            done = k
+            yield lname, ("final" if k == T else f"step{k}"), w, thr
+        if not spk:
+            table = O.layer_forward_clamped(X, w, thr)
+
+
+def test_training_restatement_is_bit_exact_with_pinned_gemv_order():
+    """Reference STDP / clamps / ITP / homeostasis / annealing (its own torch code) with only the Linear's
+    summation order pinned to the ascending fmaf chain: the oracle must agree bit for bit at every snapshot."""
+    G = np.load(f"{GOLDEN}/train_example_chain.npz")
+    n = 0
+    for lname, tag, w, thr in _train_replay(G):
+        assert np.array_equal(w, G[f"{lname}_w_{tag}"]), (lname, tag)
+        assert np.array_equal(thr, G[f"{lname}_thr_{tag}"].reshape(-1)), (lname, tag)
+        n += 1
+    assert n == 12
+
+
+def test_training_matches_unmodified_reference_within_gemv_order_noise():
+    """Against the completely unmodified reference run (torch's MKL GEMV order, which is unspecified) the
+    weights agree to 1e-6 absolute (float32 scores tolerance of the north star is 1e-5); thresholds exactly."""
+    G = np.load(f"{GOLDEN}/train_example.npz")
+    for lname, tag, w, thr in _train_replay(G):
+        assert np.allclose(w, G[f"{lname}_w_{tag}"], rtol=0, atol=1e-6), (lname, tag)
+        assert np.array_equal(thr, G[f"{lname}_thr_{tag}"].reshape(-1))
+        assert np.array_equal(w == 0, G[f"{lname}_w_{tag}"] == 0)          # sparsity pattern is preserved

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 2
+#define LENS_AMD_ABI_VERSION 3
 
 enum {
     LENS_OK = 0,
@@ -159,6 +159,44 @@ int lens_seqmatch_topk(const float *d_counts, int Q, int ldo, int n_places, int 
  */
 int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Qs, int K,
                     int32_t *d_idx_out, float *d_val_out, void *stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Training path (`python main.py --train_model`), SURVEY.md 8f-1 / BASELINE config 5.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Padded fan-in the training kernel uses for n_in inputs (64/128/208/256; 0 = n_in > 256, unsupported).
+ * x_table / mpre_table rows must be zero padded to a leading dimension >= this value. */
+int lens_train_in_pad(int n_in);
+
+/*
+ * Frozen-layer pass for training a later layer.  Replaces lens/train_model.py:163-168
+ * (`spikes = layer.w(spikes); spikes = clamp_spikes(spikes, layer)`, lens/src/blitnet.py:177-181) for all
+ * S samples at once:  y[s][o] = clamp(sum_n x[s][n]*w[o][n] - thr[o], 0, 1), Linear = ascending fmaf chain.
+ * d_x [S][ldx], d_w [n_out][ldw] (state_dict layout), d_thr [n_out], d_y [S][ldy].
+ */
+int lens_layer_forward_clamped(const float *d_x, int S, int ldx, const float *d_w, int ldw, const float *d_thr,
+                               int n_in, int n_out, float *d_y, int ldy, void *stream);
+
+/*
+ * T consecutive training steps of one layer, in place.  Replaces the body of LENS_Trainer.train_layer
+ * (lens/train_model.py:157-181) and calc_stdp (lens/src/blitnet.py:183-254): forward, clamp, STDP
+ * (normal rule, or the spike-forcing rule when d_force_idx != NULL), sign-masked weight clamps, ITP
+ * threshold update and inhibitory homeostasis, each tensor expression in its written order in f32.
+ *   d_w [n_out][ldw], d_thr [n_out]                  in/out (state_dict layout of <layer>.w.weight / .thr)
+ *   d_exc, d_inh uint8 [n_out][n_in]                 havconnCombinedExc / Inh (fixed at construction)
+ *   d_fire_rate [n_out], have_rate                   layer.fire_rate, layer.have_rate
+ *   d_x_table [S][ldx]                               the layer's input vector per sample (zero padded rows)
+ *   d_mpre_table [S][ldx] (spike forcing only)       x_table / prev_layer.fire_rate   (blitnet.py:201-205)
+ *   d_order int32 [T]                                sample presented at each step
+ *   d_force_idx int32 [T] or NULL                    int(labels / filter) per step (spike forcing = output layer)
+ *   d_eta_ip, d_eta_stdp float [T]                   learning rates in effect at each step (annealing schedule)
+ * n_in <= 256 (the weight row of a neuron lives in the registers of one lane).
+ */
+int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, const uint8_t *d_inh,
+                     const float *d_fire_rate, int have_rate, const float *d_x_table, const float *d_mpre_table, int ldx,
+                     const int32_t *d_order, const int32_t *d_force_idx, const float *d_eta_ip, const float *d_eta_stdp,
+                     int n_out, int n_in, int T, void *stream);
 
 #ifdef __cplusplus
 }

@@ -606,6 +606,126 @@ __global__ void __launch_bounds__(256) k_topk_merge(const int32_t *__restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// f1. Training (`--train_model`): lens/train_model.py:157-177 + calc_stdp, lens/src/blitnet.py:183-254.
+//   Every output neuron of a layer evolves independently given the sample sequence (its forward value,
+//   STDP row, threshold and homeostasis only involve its own weight row), so one LANE owns one row,
+//   keeps it in registers for all T steps and the per-step input vector is wave-uniform (scalar loads).
+//   IN_PAD: padded fan-in (registers per lane); x_table / mpre_table rows are zero padded to ldx >= IN_PAD.
+// ------------------------------------------------------------------------------------------
+struct TrainArgs {
+    float *w; int ldw;
+    float *thr;
+    const uint8_t *exc; const uint8_t *inh;
+    const float *fire_rate; int have_rate;
+    const float *x_table; const float *mpre_table; int ldx;
+    const int32_t *order; const int32_t *force_idx;
+    const float *eta_ip; const float *eta_stdp;
+    int n_out; int n_in; int T;
+};
+
+template <int IN_PAD, bool SPK>
+__global__ void __launch_bounds__(64) k_train_layer(TrainArgs a)
+{
+    constexpr int NB = (IN_PAD + 31) / 32;
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = o < a.n_out;
+    float w[IN_PAD];
+    uint32_t eb[NB], ib[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { eb[b] = 0u; ib[b] = 0u; }
+#pragma unroll
+    for (int n = 0; n < IN_PAD; ++n) {
+        const bool in = valid && n < a.n_in;
+        w[n] = in ? a.w[(size_t)o * a.ldw + n] : 0.0f;
+        if (in && a.exc[(size_t)o * a.n_in + n]) eb[n >> 5] |= 1u << (n & 31);
+        if (in && a.inh[(size_t)o * a.n_in + n]) ib[n >> 5] |= 1u << (n & 31);
+    }
+    float thr = valid ? a.thr[o] : 0.0f;
+    const float fr = valid ? a.fire_rate[o] : 0.0f;
+
+    for (int t = 0; t < a.T; ++t) {
+        const int s = a.order[t];
+        const float *pre = a.x_table + (size_t)s * a.ldx;
+        const float eta = a.eta_stdp[t], eip = a.eta_ip[t];
+        float acc = 0.0f;                                    // y = layer.w(x): ascending fmaf chain
+#pragma unroll
+        for (int n = 0; n < IN_PAD; ++n) acc = __builtin_fmaf(pre[n], w[n], acc);
+        const float y = acc;                                 // spikes_noclp
+        float post = y - thr;                                // clamp_spikes
+        post = __builtin_fminf(__builtin_fmaxf(post, 0.0f), 1.0f);
+        float lx = 0.0f;                                     // layer.x
+        if constexpr (SPK) {                                 // blitnet.py:185-215
+            lx = (o == a.force_idx[t]) ? 0.5f : 0.0f;
+            float xd = lx - post;
+            xd = __builtin_fminf(__builtin_fmaxf(xd, 0.0f), 1.0f);
+            if (__builtin_amdgcn_ballot_w64(xd > 0.0f) != 0) {   // only the wavefront that owns row idx
+                const float *mp = a.mpre_table + (size_t)s * a.ldx;
+#pragma unroll
+                for (int n = 0; n < IN_PAD; ++n) {
+                    // exc: ((mpre*xd)*1)*eta ; inh: ((-mpre*xd)*1)*(eta*-1) -- the same bits
+                    const float dw = (mp[n] * xd) * eta;
+                    const bool conn = ((eb[n >> 5] | ib[n >> 5]) >> (n & 31)) & 1u;
+                    w[n] = w[n] + (conn ? dw : 0.0f);
+                }
+            }
+        } else {                                             // blitnet.py:218-231
+            const float d = 0.5f - post;
+            const float de = d * eta, nde = d * (eta * -1.0f);
+            const bool b2 = post > 0.0f;
+#pragma unroll
+            for (int n = 0; n < IN_PAD; ++n) {
+                if (pre[n] > 0.0f) {                         // wave-uniform
+                    const bool e = (eb[n >> 5] >> (n & 31)) & 1u, i = (ib[n >> 5] >> (n & 31)) & 1u;
+                    const float dw = e ? de : (i ? nde : 0.0f);
+                    w[n] = w[n] + (b2 ? dw : 0.0f);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < IN_PAD; ++n) {                   // blitnet.py:234-235
+            const bool e = (eb[n >> 5] >> (n & 31)) & 1u, i = (ib[n >> 5] >> (n & 31)) & 1u;
+            const float ce = __builtin_fminf(__builtin_fmaxf(w[n], 1e-06f), 10.0f);
+            const float ci = __builtin_fminf(__builtin_fmaxf(w[n], -10.0f), -1e-06f);
+            w[n] = e ? ce : (i ? ci : w[n]);
+        }
+        if (a.have_rate && eip > 0.0f) {                     // blitnet.py:239-243
+            thr = thr + eip * (lx - fr);
+            thr = (thr < 0.0f) ? 0.0f : thr;
+        }
+        if (eta != 0.0f) {                                   // blitnet.py:246-251
+#pragma unroll
+            for (int n = 0; n < IN_PAD; ++n) {
+                const float iw = (w[n] > 0.0f) ? 0.0f : w[n];
+                w[n] = w[n] + ((y * iw) * eta) * 50.0f;
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int n = 0; n < IN_PAD; ++n)
+            if (n < a.n_in) a.w[(size_t)o * a.ldw + n] = w[n];
+        a.thr[o] = thr;
+    }
+}
+
+// y[s][o] = clamp(chain_n fmaf(x[s][n], w[o][n]) - thr[o], 0, 1)  (train_model.py:163-168)
+__global__ void __launch_bounds__(256) k_layer_forward_clamped(const float *__restrict__ x, int S, int ldx,
+                                                               const float *__restrict__ w, int ldw,
+                                                               const float *__restrict__ thr, int n_in, int n_out,
+                                                               float *__restrict__ y, int ldy)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)S * n_out) return;
+    const int s = (int)(i / n_out), o = (int)(i - (long long)s * n_out);
+    float acc = 0.0f;
+    for (int n = 0; n < n_in; ++n) acc = __builtin_fmaf(x[(size_t)s * ldx + n], w[(size_t)o * ldw + n], acc);
+    float v = acc - thr[o];
+    v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f);
+    y[(size_t)s * ldy + o] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
@@ -840,6 +960,56 @@ int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Q
     if (Qs == 0) return LENS_OK;
     hipLaunchKernelGGL(k_topk_merge, dim3((Qs + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_idx_in, d_val_in, R,
                        Qs, K, d_idx_out, d_val_out);
+    return (int)hipGetLastError();
+}
+
+
+int lens_train_in_pad(int n_in)
+{
+    for (int p : {64, 128, 208, 256})
+        if (n_in <= p) return p;
+    return 0;
+}
+
+int lens_layer_forward_clamped(const float *d_x, int S, int ldx, const float *d_w, int ldw, const float *d_thr,
+                               int n_in, int n_out, float *d_y, int ldy, void *stream)
+{
+    if (!d_x || !d_w || !d_thr || !d_y) return LENS_ERR_NULL;
+    if (S < 0 || n_in <= 0 || n_out <= 0 || ldx < n_in || ldw < n_in || ldy < n_out) return LENS_ERR_SIZE;
+    if (S == 0) return LENS_OK;
+    const long long total = (long long)S * n_out;
+    hipLaunchKernelGGL(k_layer_forward_clamped, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_x, S, ldx, d_w, ldw, d_thr, n_in, n_out, d_y, ldy);
+    return (int)hipGetLastError();
+}
+
+int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, const uint8_t *d_inh,
+                     const float *d_fire_rate, int have_rate, const float *d_x_table, const float *d_mpre_table, int ldx,
+                     const int32_t *d_order, const int32_t *d_force_idx, const float *d_eta_ip, const float *d_eta_stdp,
+                     int n_out, int n_in, int T, void *stream)
+{
+    if (!d_w || !d_thr || !d_exc || !d_inh || !d_fire_rate || !d_x_table || !d_order || !d_eta_ip || !d_eta_stdp)
+        return LENS_ERR_NULL;
+    const bool spk = d_force_idx != nullptr;
+    if (spk && !d_mpre_table) return LENS_ERR_NULL;
+    if (n_out <= 0 || n_in <= 0 || T < 0 || ldw < n_in) return LENS_ERR_SIZE;
+    const int pad = lens_train_in_pad(n_in);
+    if (!pad) return LENS_ERR_UNSUPPORTED;
+    if (ldx < pad) return LENS_ERR_SIZE;
+    if (T == 0) return LENS_OK;
+    TrainArgs a{d_w, ldw, d_thr, d_exc, d_inh, d_fire_rate, have_rate ? 1 : 0, d_x_table, d_mpre_table, ldx,
+                d_order, d_force_idx, d_eta_ip, d_eta_stdp, n_out, n_in, T};
+    const dim3 grid((n_out + 63) / 64), block(64);
+    hipStream_t st = (hipStream_t)stream;
+#define LENS_TRAIN_CASE(P)                                                                    \
+    case P:                                                                                   \
+        if (spk) hipLaunchKernelGGL((k_train_layer<P, true>), grid, block, 0, st, a);         \
+        else hipLaunchKernelGGL((k_train_layer<P, false>), grid, block, 0, st, a);            \
+        break;
+    switch (pad) {
+        LENS_TRAIN_CASE(64) LENS_TRAIN_CASE(128) LENS_TRAIN_CASE(208) LENS_TRAIN_CASE(256)
+    }
+#undef LENS_TRAIN_CASE
     return (int)hipGetLastError();
 }
 

@@ -233,3 +233,52 @@ def topk_merge(idx_in, val_in):
     st = _lib.lib().lens_topk_merge(_ptr(idx_in), _ptr(val_in), R, Qs, K, _ptr(idx), _ptr(val), _stream())
     _lib.check(st, "lens_topk_merge")
     return idx, val
+
+
+# --------------------------------------------------------------------------------------------
+# training path (SURVEY 8f-1): thin wrappers over lens_layer_forward_clamped / lens_train_layer
+# --------------------------------------------------------------------------------------------
+def train_in_pad(n_in):
+    pad = int(_lib.lib().lens_train_in_pad(int(n_in)))
+    if pad == 0:
+        raise _lib.LensAmdError(f"training kernel supports a fan-in of at most 256 inputs, got {n_in}")
+    return pad
+
+
+def pad_table(x, ld):
+    """[S, n] float32 (any device) -> zero padded contiguous [S, ld] on the same device."""
+    S, n = x.shape
+    out = torch.zeros((S, ld), dtype=torch.float32, device=x.device)
+    out[:, :n] = x
+    return out
+
+
+def layer_forward_clamped(x_table, n_in, w, thr):
+    """clamp(w(x) - thr, 0, 1) for every sample; x_table [S, ld>=n_in] device, w [n_out, n_in], thr [n_out]."""
+    _need_cuda(x_table, "x_table")
+    S, ldx = x_table.shape
+    n_out = w.shape[0]
+    y = torch.empty((S, n_out), dtype=torch.float32, device=x_table.device)
+    st = _lib.lib().lens_layer_forward_clamped(_ptr(x_table), S, ldx, _ptr(w), w.shape[1], _ptr(thr), n_in, n_out,
+                                               _ptr(y), n_out, _stream())
+    _lib.check(st, "lens_layer_forward_clamped")
+    return y
+
+
+def train_layer(w, thr, exc, inh, fire_rate, have_rate, x_table, order, eta_ip, eta_stdp, force_idx=None, mpre_table=None):
+    """T = len(order) training steps in place on the device tensors w [n_out,n_in] and thr [n_out]."""
+    for t, name in ((w, "w"), (thr, "thr"), (x_table, "x_table"), (order, "order")):
+        _need_cuda(t, name)
+    n_out, n_in = w.shape
+    assert w.is_contiguous() and thr.is_contiguous() and thr.numel() == n_out
+    assert exc.dtype == torch.uint8 and inh.dtype == torch.uint8 and exc.shape == w.shape and inh.shape == w.shape
+    assert order.dtype == torch.int32 and eta_ip.dtype == torch.float32 and eta_stdp.dtype == torch.float32
+    assert x_table.shape[1] >= train_in_pad(n_in)
+    if force_idx is not None:
+        assert force_idx.dtype == torch.int32 and mpre_table is not None and mpre_table.shape == x_table.shape
+    st = _lib.lib().lens_train_layer(_ptr(w), n_in, _ptr(thr), _ptr(exc.contiguous()), _ptr(inh.contiguous()),
+                                     _ptr(fire_rate), int(have_rate), _ptr(x_table), _ptr(mpre_table), x_table.shape[1],
+                                     _ptr(order), _ptr(force_idx), _ptr(eta_ip), _ptr(eta_stdp),
+                                     n_out, n_in, order.numel(), _stream())
+    _lib.check(st, "lens_train_layer")
+    return w, thr

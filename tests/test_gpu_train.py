@@ -1,0 +1,94 @@
+"""GPU parity of the training kernels: bit-exact against the oracle and against the golden run
+of the reference's own train_model.py/blitnet.py with the Linear's summation order pinned to the chain."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _run_layer(G, lname, spk, table_dev, n_in, steps, labels):
+    from oracle import oracle as O
+    from lens_amd.engine import train_layer, train_in_pad, pad_table
+    order = G[f"{lname}_order"].reshape(-1)
+    T = len(order)
+    eip, est = O.anneal_schedule(float(G[f"{lname}_eta0"][0]), float(G[f"{lname}_eta0"][1]), T)
+    w = _dev(G[f"{lname}_w0"]); thr = _dev(G[f"{lname}_thr0"].reshape(-1))
+    exc = _dev(G[f"{lname}_exc"].astype(np.uint8)); inh = _dev(G[f"{lname}_inh"].astype(np.uint8))
+    fr = _dev(G[f"{lname}_fire_rate"].reshape(-1))
+    have_rate = bool(G[f"{lname}_fire_rate"].reshape(-1)[0] > 0)
+    ld = train_in_pad(n_in)
+    xt = pad_table(table_dev, ld)
+    mp = None
+    if spk:
+        pfr = torch.from_numpy(G["feature_layer_fire_rate"].reshape(-1))
+        mp = pad_table((table_dev.cpu() / pfr).cuda(), ld)       # blitnet.py:204, IEEE division on the host
+    done = 0
+    for k in steps:
+        kk = T if k == "final" else k
+        fi = _dev(labels[order[done:kk]].astype(np.int32)) if spk else None
+        train_layer(w, thr, exc, inh, fr, have_rate, xt, _dev(order[done:kk].astype(np.int32)),
+                    _dev(eip[done:kk]), _dev(est[done:kk]), force_idx=fi, mpre_table=mp)
+        done = kk
+        yield k, w.cpu().numpy(), thr.cpu().numpy()
+
+
+def test_training_kernels_match_pinned_reference_run():
+    from lens_amd.engine import layer_forward_clamped
+    G = np.load(f"{GOLDEN}/train_example_chain.npz")
+    X = _dev(G["x_table"])
+    labels = G["labels"]
+    steps = (1, 2, 10, 11, 37, "final")
+    w = thr = None
+    for k, w, thr in _run_layer(G, "feature_layer", False, X, X.shape[1], steps, labels):
+        tag = "final" if k == "final" else f"step{k}"
+        assert np.array_equal(w, G[f"feature_layer_w_{tag}"]), tag
+        assert np.array_equal(thr, G[f"feature_layer_thr_{tag}"].reshape(-1)), tag
+    pre = layer_forward_clamped(X, X.shape[1], _dev(w), _dev(thr))
+    from oracle import oracle as O
+    assert np.array_equal(pre.cpu().numpy(), O.layer_forward_clamped(G["x_table"], w, thr))
+    for k, w2, thr2 in _run_layer(G, "output_layer", True, pre, pre.shape[1], steps, labels):
+        tag = "final" if k == "final" else f"step{k}"
+        assert np.array_equal(w2, G[f"output_layer_w_{tag}"]), tag
+        assert np.array_equal(thr2, G[f"output_layer_thr_{tag}"].reshape(-1)), tag
+
+
+def test_training_kernels_match_oracle_on_random_layers():
+    """Ragged sizes, homeostasis sign flips (large negative weights), thresholds, both STDP rules."""
+    from oracle import oracle as O
+    from lens_amd.engine import train_layer, train_in_pad, pad_table
+    rng = np.random.default_rng(5)
+    for n_out, n_in, spk in ((70, 33, False), (200, 100, False), (130, 200, True), (5, 256, True)):
+        S, T = 11, 60
+        w0 = (rng.standard_normal((n_out, n_in)) * 0.6).astype(np.float32)
+        w0[rng.random((n_out, n_in)) < 0.3] = 0
+        w0[0, :3] = [-4.5, 3.0, -3.9]                              # drives y < -2: homeostasis flips inhibitory signs
+        exc, inh = (w0 > 0).astype(np.uint8), (w0 < 0).astype(np.uint8)
+        thr0 = rng.random(n_out).astype(np.float32) * 0.5
+        fr = (0.4 + 0.2 * np.arange(1, n_out + 1) / n_out).astype(np.float32)
+        x = (rng.random((S, n_in)) * (rng.random((S, n_in)) < 0.6)).astype(np.float32)
+        order = rng.integers(0, S, T).astype(np.int32)
+        eip, est = O.anneal_schedule(0.02, 0.01, T)
+        kw_o, kw_g = {}, {}
+        if spk:
+            fi = rng.integers(0, n_out, T).astype(np.int32)
+            pfr = (0.3 + rng.random(n_in) * 0.4).astype(np.float32)
+            kw_o = dict(force_idx=fi, prev_fire_rate=pfr)
+            ld = train_in_pad(n_in)
+            kw_g = dict(force_idx=_dev(fi), mpre_table=pad_table((torch.from_numpy(x) / torch.from_numpy(pfr)).cuda(), ld))
+        rw, rthr = O.train_layer(w0, thr0, exc, inh, fr, x, order, eip, est, **kw_o)
+        w, thr = _dev(w0), _dev(thr0)
+        train_layer(w, thr, _dev(exc), _dev(inh), _dev(fr), True, pad_table(_dev(x), train_in_pad(n_in)), _dev(order),
+                    _dev(eip), _dev(est), **kw_g)
+        assert np.array_equal(w.cpu().numpy(), rw), (n_out, n_in, spk)
+        assert np.array_equal(thr.cpu().numpy(), rthr)
+        assert not np.array_equal(rw, w0)

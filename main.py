@@ -4,9 +4,9 @@ reference's main.py (lines 27-38, 40-76, 85-186), served by the MI355X hot path 
 
     python main.py --sim_mat --matching            # bundled example, GPU
 
-Only the inference-and-matching mode is implemented.  The neuromorphic-hardware modes
-(--event_driven, --simulated_speck, --collect_data) and --train_model stop with a clear message;
---nocuda is accepted but refused at model construction (this build has no CPU execution path).
+Inference-and-matching and --train_model are implemented.  The neuromorphic-hardware modes
+(--event_driven, --simulated_speck, --collect_data) stop with a clear message; --nocuda is accepted but
+refused at model construction (this build has no CPU execution path).
 """
 import argparse
 import sys
@@ -48,7 +48,7 @@ _VALUE_FLAGS = [
     ("timebin", int, 250, "time steps of the rate-coded simulation per query"),
 ]
 _SWITCHES = [
-    ("train_model", "train a new network (not part of this build)"),
+    ("train_model", "train a new network on the reference traverse"),
     ("sim_mat", "plot the similarity matrix"),
     ("PR_curve", "plot a precision-recall curve"),
     ("matching", "evaluate Recall@N against the ground truth"),
@@ -88,8 +88,9 @@ def initialize_and_run_model(args):
             sys.exit(f"--{flag} drives SynSense Speck hardware through samna; lens_amd implements the "
                      "GPU inference-and-matching path only")
     if args.train_model:
-        sys.exit("--train_model is not part of this build yet (training kernels: SURVEY.md 8f-1); "
-                 "use a model trained with the reference, the .pth format is identical")
+        from lens_amd.train_model import LENS_Trainer, train_model
+        model = LENS_Trainer(args)
+        return train_model(model, generate_model_name(model))
     from lens_amd.run_model import LENS, run_inference
     model = LENS(args)
     return run_inference(model, generate_model_name(model))

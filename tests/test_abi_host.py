@@ -206,3 +206,31 @@ def test_synthetic_generators_are_deterministic():
     w = torch.randn(10, 6)
     db = synthetic_database(w, 25)
     assert db.shape == (25, 6) and torch.equal(db, synthetic_database(w, 25))
+
+
+def test_training_mode_init_and_preprocessing_match_the_reference():
+    """Same seeds -> the mirror's SNNLayer training-mode construction and the training-image preprocessing are
+    bit-identical to what the reference built in the golden run (its w0, thr0, fire_rate, masks, x_table)."""
+    from lens_amd.blitnet import SNNLayer
+    from lens_amd.train_model import training_inputs, anneal_schedule
+    from lens_amd.dataset import CustomImageDataset
+    G = np.load(os.path.join(GOLDEN, "train_example.npz"))
+    places, epochs, seed = (int(v) for v in G["meta"][:3])
+    torch.manual_seed(seed); np.random.seed(seed)
+    feat = SNNLayer(dims=[100, 200], thr_range=[0, 0.75], fire_rate=[0.4, 0.6], ip_rate=0.02, stdp_rate=0.01, p=[0.35, 0.75])
+    out = SNNLayer(dims=[200, places], thr_range=[0, 0.5], fire_rate=[0.5, 0.5], ip_rate=0.02, stdp_rate=0.01, p=[1.0, 1.0],
+                   spk_force=True)
+    for name, L in (("feature_layer", feat), ("output_layer", out)):
+        assert np.array_equal(L.w.weight.detach().numpy(), G[f"{name}_w0"]), name
+        assert np.array_equal(L.thr.detach().numpy(), G[f"{name}_thr0"])
+        assert np.array_equal(L.fire_rate.numpy(), G[f"{name}_fire_rate"])
+        assert np.array_equal(L.havconnCombinedExc.numpy(), G[f"{name}_exc"])
+        assert np.array_equal(L.havconnCombinedInh.numpy(), G[f"{name}_inh"])
+        T = G[f"{name}_order"].size
+        eip, est, _, _ = anneal_schedule(L, T)
+        assert np.array_equal(torch.stack([eip, est], 1).numpy(), G[f"{name}_eta_used"])
+    ds = CustomImageDataset(os.path.join(ROOT, "lens/dataset/example-reference.csv"),
+                            os.path.join(ROOT, "lens/dataset/example/davis128/example-reference"), max_samples=places, test=False)
+    x = training_inputs(ds.frames(), 8)
+    assert np.array_equal(x.numpy(), G["x_table"])
+    assert np.array_equal(np.array([ds[i][1] for i in range(len(ds))]), G["labels"])

@@ -92,3 +92,59 @@ def test_training_kernels_match_oracle_on_random_layers():
         assert np.array_equal(w.cpu().numpy(), rw), (n_out, n_in, spk)
         assert np.array_equal(thr.cpu().numpy(), rthr)
         assert not np.array_equal(rw, w0)
+
+
+def test_trainer_mirror_reproduces_the_reference_training_run(tmp_path):
+    """LENS_Trainer (host mirror) driven with the golden run's seeds and sample orders ends with the golden run's
+    weights, bit for bit (the run whose Linear order is pinned), and within 1e-6 of the unmodified reference."""
+    import os
+    import main
+    from helpers import ROOT
+    from lens_amd.train_model import LENS_Trainer, training_inputs
+    from lens_amd.dataset import CustomImageDataset
+    G = np.load(f"{GOLDEN}/train_example_chain.npz")
+    G0 = np.load(f"{GOLDEN}/train_example.npz")
+    places, epochs, seed = (int(v) for v in G["meta"][:3])
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        os.makedirs("lens")
+        os.symlink(os.path.join(ROOT, "lens", "dataset"), "lens/dataset")
+        a = main.build_parser().parse_args(["--train_model", "--reference_places", str(places), "--query_places", str(places),
+                                            "--epoch_feat", str(epochs), "--epoch_out", str(epochs)])
+        torch.manual_seed(seed); np.random.seed(seed)
+        model = LENS_Trainer(a)
+        ds = CustomImageDataset(model.dataset_file, model.reference_dir, max_samples=places, test=False)
+        x = training_inputs(ds.frames(), 8)
+        labels = torch.tensor([ds[i][1] for i in range(len(ds))])
+        model.train_layer(x, labels, model.feature_layer, prev_layers=[], orders=G["feature_layer_order"])
+        model.train_layer(x, labels, model.output_layer, prev_layers=["feature_layer"], orders=G["output_layer_order"])
+        for name in ("feature_layer", "output_layer"):
+            L = getattr(model, name)
+            assert np.array_equal(L.w.weight.detach().numpy(), G[f"{name}_w_final"]), name
+            assert np.array_equal(L.thr.detach().numpy(), G[f"{name}_thr_final"])
+            assert np.allclose(L.w.weight.detach().numpy(), G0[f"{name}_w_final"], rtol=0, atol=1e-6)
+        model.save_model("m.pth")
+        sd = torch.load("m.pth", weights_only=True)
+        assert set(sd) == {"feature_layer.thr", "feature_layer.w.weight", "output_layer.thr", "output_layer.w.weight"}
+    finally:
+        os.chdir(cwd)
+
+
+def test_cli_train_then_infer(tmp_path):
+    """`python main.py --train_model` writes ./lens/models/<name>.pth that the inference CLI then loads."""
+    import os
+    import main
+    from helpers import ROOT
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        os.makedirs("lens")
+        os.symlink(os.path.join(ROOT, "lens", "dataset"), "lens/dataset")
+        torch.manual_seed(0); np.random.seed(0)
+        main.parse_network(["--train_model", "--epoch_feat", "8", "--epoch_out", "8"])
+        assert os.path.exists("lens/models/example-reference_LENS_IN100_FN200_DB100.pth")
+        R = main.parse_network(["--matching"])          # the GT file is 100x100, so the full traverse is used
+        assert len(R) == 6 and all(0.0 <= r <= 1.0 for r in R) and R[-1] >= R[0]
+    finally:
+        os.chdir(cwd)

@@ -183,8 +183,9 @@ int lens_layer_forward_clamped(const float *d_x, int S, int ldx, const float *d_
  * (lens/train_model.py:157-181) and calc_stdp (lens/src/blitnet.py:183-254): forward, clamp, STDP
  * (normal rule, or the spike-forcing rule when d_force_idx != NULL), sign-masked weight clamps, ITP
  * threshold update and inhibitory homeostasis, each tensor expression in its written order in f32.
- *   d_w [n_out][ldw], d_thr [n_out]                  in/out (state_dict layout of <layer>.w.weight / .thr)
- *   d_exc, d_inh uint8 [n_out][n_in]                 havconnCombinedExc / Inh (fixed at construction)
+ *   d_w [n_out][ldw], d_thr [n_out]                  in/out: <layer>.w.weight rows ZERO PADDED to ldw >= lens_train_in_pad(n_in)
+ *                                                    (ldw % 4 == 0, 16-byte aligned; the padding is written back as zeros), <layer>.thr
+ *   d_exc, d_inh uint8 [n_out][ldm]                  havconnCombinedExc / Inh (fixed at construction), rows zero padded, ldm >= in_pad
  *   d_fire_rate [n_out], have_rate                   layer.fire_rate, layer.have_rate
  *   d_x_table [S][ldx]                               the layer's input vector per sample (zero padded rows)
  *   d_mpre_table [S][ldx] (spike forcing only)       x_table / prev_layer.fire_rate   (blitnet.py:201-205)
@@ -193,7 +194,7 @@ int lens_layer_forward_clamped(const float *d_x, int S, int ldx, const float *d_
  *   d_eta_ip, d_eta_stdp float [T]                   learning rates in effect at each step (annealing schedule)
  * n_in <= 256 (the weight row of a neuron lives in the registers of one lane).
  */
-int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, const uint8_t *d_inh,
+int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, const uint8_t *d_inh, int ldm,
                      const float *d_fire_rate, int have_rate, const float *d_x_table, const float *d_mpre_table, int ldx,
                      const int32_t *d_order, const int32_t *d_force_idx, const float *d_eta_ip, const float *d_eta_stdp,
                      int n_out, int n_in, int T, void *stream);

@@ -38,7 +38,7 @@ SIGNATURES = {
     "lens_topk_merge": (_i, [_c_p, _c_p, _i, _i, _i, _c_p, _c_p, _c_p]),
     "lens_train_in_pad": (_i, [_i]),
     "lens_layer_forward_clamped": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _c_p]),
-    "lens_train_layer": (_i, [_c_p, _i, _c_p, _c_p, _c_p, _c_p, _i, _c_p, _c_p, _i, _c_p, _c_p, _c_p, _c_p,
+    "lens_train_layer": (_i, [_c_p, _i, _c_p, _c_p, _c_p, _i, _c_p, _i, _c_p, _c_p, _i, _c_p, _c_p, _c_p, _c_p,
                               _i, _i, _i, _c_p]),
 }
 

@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(256) k_topk_merge(const int32_t *__restrict__ 
 struct TrainArgs {
     float *w; int ldw;
     float *thr;
-    const uint8_t *exc; const uint8_t *inh;
+    const uint8_t *exc; const uint8_t *inh; int ldm;
     const float *fire_rate; int have_rate;
     const float *x_table; const float *mpre_table; int ldx;
     const int32_t *order; const int32_t *force_idx;
@@ -625,88 +625,200 @@ struct TrainArgs {
     int n_out; int n_in; int T;
 };
 
-template <int IN_PAD, bool SPK>
+// Stage one table row (IN_PAD floats, zero padded) into this wavefront's LDS buffer: lane l loads elements
+// 4l..4l+3 with one 16-byte load; returns, per component c, the ballot of (element 4l+c > 0).
+template <int IN_PAD>
+__device__ __forceinline__ void stage_row(const float *row, float *lds, int lane, uint64_t (&pos)[4])
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane * 4 < IN_PAD) v = *reinterpret_cast<const float4 *>(row + lane * 4);
+    pos[0] = __ballot(v.x > 0.0f); pos[1] = __ballot(v.y > 0.0f);
+    pos[2] = __ballot(v.z > 0.0f); pos[3] = __ballot(v.w > 0.0f);
+    if (lane * 4 < IN_PAD) *reinterpret_cast<float4 *>(lds + lane * 4) = v;
+}
+
+// Per-element sign masks are kept as packed bits; selects are integer blends (v_bfe_i32 gives an all-ones /
+// all-zeros word, v_bfi_b32 blends), so no per-element lane masks (SGPR pairs) are ever materialised.
+__device__ __forceinline__ uint32_t bit_mask(uint32_t word, int n) { return (uint32_t)__builtin_amdgcn_sbfe((int)word, n & 31, 1); }
+__device__ __forceinline__ float blend(uint32_t m, float a, float b)   // m ? a : b, bitwise
+{
+    return __uint_as_float((m & __float_as_uint(a)) | (~m & __float_as_uint(b)));
+}
+
+// value of the neighbouring lane (lane ^ 1) via DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor1(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+}
+
+// LPR = lanes per weight row (1 or 2).  With LPR == 2 (fan-in > 128, which would not fit the 256 architectural
+// VGPRs of one lane) lane 2r holds columns [0, HP) of row r and lane 2r+1 columns [HP, 2 HP); the forward chain
+// runs over the left half, is handed to the right lane and continues there, so it is still one ascending chain.
+template <int IN_PAD, int LPR, bool SPK>
 __global__ void __launch_bounds__(64) k_train_layer(TrainArgs a)
 {
-    constexpr int NB = (IN_PAD + 31) / 32;
-    const int o = blockIdx.x * 64 + threadIdx.x;
+    static_assert(IN_PAD % (4 * LPR) == 0 && IN_PAD <= 256, "one 16-byte load per lane stages a row");
+    constexpr int HP = IN_PAD / LPR;              // columns per lane
+    constexpr int NB = (HP + 31) / 32;
+    constexpr int RPW = 64 / LPR;                 // rows per wavefront
+    __shared__ __attribute__((aligned(16))) float s_row[IN_PAD];   // the step's input vector, read back as broadcasts
+    const int lane = threadIdx.x;
+    const int h = (LPR == 2) ? (lane & 1) : 0;
+    const int o = blockIdx.x * RPW + (LPR == 2 ? (lane >> 1) : lane);
     const bool valid = o < a.n_out;
-    float w[IN_PAD];
+    const int col0 = h * HP;
+    float w[HP];
     uint32_t eb[NB], ib[NB];
+    {   // rows are zero padded to ldw / ldm >= IN_PAD by the caller: unpredicated loads, row index clamped
+        const size_t ro = (size_t)(valid ? o : 0);
+        const float *wr = a.w + ro * a.ldw + col0;
+        const uint8_t *er = a.exc + ro * a.ldm + col0, *ir = a.inh + ro * a.ldm + col0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { eb[b] = 0u; ib[b] = 0u; }
+        for (int k4 = 0; k4 < HP; k4 += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(wr + k4);
+            w[k4] = v.x; w[k4 + 1] = v.y; w[k4 + 2] = v.z; w[k4 + 3] = v.w;
+        }
 #pragma unroll
-    for (int n = 0; n < IN_PAD; ++n) {
-        const bool in = valid && n < a.n_in;
-        w[n] = in ? a.w[(size_t)o * a.ldw + n] : 0.0f;
-        if (in && a.exc[(size_t)o * a.n_in + n]) eb[n >> 5] |= 1u << (n & 31);
-        if (in && a.inh[(size_t)o * a.n_in + n]) ib[n >> 5] |= 1u << (n & 31);
+        for (int b = 0; b < NB; ++b) {
+            uint32_t e = 0u, i = 0u;
+            const int lim = (HP - 32 * b) < 32 ? (HP - 32 * b) : 32;
+#pragma unroll 1
+            for (int j = 0; j < lim; ++j) {
+                e |= (er[32 * b + j] ? 1u : 0u) << j;
+                i |= (ir[32 * b + j] ? 1u : 0u) << j;
+            }
+            eb[b] = valid ? e : 0u;
+            ib[b] = valid ? i : 0u;
+        }
+        if (!valid) {
+#pragma unroll
+            for (int k = 0; k < HP; ++k) w[k] = 0.0f;
+        }
     }
     float thr = valid ? a.thr[o] : 0.0f;
     const float fr = valid ? a.fire_rate[o] : 0.0f;
+    const float *my_row = s_row + col0;               // this lane's segment of the staged input vector
 
     for (int t = 0; t < a.T; ++t) {
+        // The packed masks are made opaque before every section that tests them: otherwise the compiler
+        // extracts all 2*HP per-element masks once and keeps them alive (hundreds of registers).
+#define LENS_REFRESH_MASKS()                                                                  \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(eb[b]), "+v"(ib[b]))
         const int s = a.order[t];
-        const float *pre = a.x_table + (size_t)s * a.ldx;
         const float eta = a.eta_stdp[t], eip = a.eta_ip[t];
+        uint64_t pos[4];
+        stage_row<IN_PAD>(a.x_table + (size_t)s * a.ldx, s_row, lane, pos);
         float acc = 0.0f;                                    // y = layer.w(x): ascending fmaf chain
 #pragma unroll
-        for (int n = 0; n < IN_PAD; ++n) acc = __builtin_fmaf(pre[n], w[n], acc);
+        for (int ph = 0; ph < LPR; ++ph) {
+            if (ph == 1) {                                           // right lane continues the left lane's chain
+                const float left = lane_xor1(acc);                   // DPP with all lanes active, then select
+                acc = (h == 1) ? left : acc;
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < HP; k4 += 4) {
+                if ((k4 & 15) == 0) __builtin_amdgcn_sched_barrier(0);   // bound live ranges of the unrolled body
+                const float4 p = *reinterpret_cast<const float4 *>(s_row + ph * HP + k4);   // wave-uniform: broadcast
+                float c = acc;
+                c = __builtin_fmaf(p.x, w[k4], c);
+                c = __builtin_fmaf(p.y, w[k4 + 1], c);
+                c = __builtin_fmaf(p.z, w[k4 + 2], c);
+                c = __builtin_fmaf(p.w, w[k4 + 3], c);
+                acc = (LPR == 1 || h == ph) ? c : acc;       // only the half that owns this segment advances
+            }
+        }
+        if (LPR == 2) {                                      // both lanes of the row hold y
+            const float right = lane_xor1(acc);
+            acc = (h == 0) ? right : acc;
+        }
         const float y = acc;                                 // spikes_noclp
         float post = y - thr;                                // clamp_spikes
         post = __builtin_fminf(__builtin_fmaxf(post, 0.0f), 1.0f);
         float lx = 0.0f;                                     // layer.x
+        // Weight clamps (blitnet.py:234-235) are no-ops on elements that are already in range.  Excitatory
+        // weights only leave their range through this step's STDP update (homeostasis adds +-0 to positive
+        // weights), so they are clamped where they are updated -- and all of them at a call's first step, where
+        // the initial weights may be below 1e-6.  Inhibitory weights are moved by homeostasis every step.
         if constexpr (SPK) {                                 // blitnet.py:185-215
             lx = (o == a.force_idx[t]) ? 0.5f : 0.0f;
             float xd = lx - post;
             xd = __builtin_fminf(__builtin_fmaxf(xd, 0.0f), 1.0f);
             if (__builtin_amdgcn_ballot_w64(xd > 0.0f) != 0) {   // only the wavefront that owns row idx
-                const float *mp = a.mpre_table + (size_t)s * a.ldx;
+                uint64_t unused[4];
+                LENS_REFRESH_MASKS();
+                stage_row<IN_PAD>(a.mpre_table + (size_t)s * a.ldx, s_row, lane, unused);
 #pragma unroll
-                for (int n = 0; n < IN_PAD; ++n) {
-                    // exc: ((mpre*xd)*1)*eta ; inh: ((-mpre*xd)*1)*(eta*-1) -- the same bits
-                    const float dw = (mp[n] * xd) * eta;
-                    const bool conn = ((eb[n >> 5] | ib[n >> 5]) >> (n & 31)) & 1u;
-                    w[n] = w[n] + (conn ? dw : 0.0f);
+                for (int k4 = 0; k4 < HP; k4 += 4) {
+                    if ((k4 & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+                    const float4 p = *reinterpret_cast<const float4 *>(my_row + k4);
+                    const float mp[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = k4 + c;
+                        // exc: ((mpre*xd)*1)*eta ; inh: ((-mpre*xd)*1)*(eta*-1) -- the same bits
+                        const float dw = (mp[c] * xd) * eta;
+                        const uint32_t me = bit_mask(eb[k >> 5], k), mi = bit_mask(ib[k >> 5], k);
+                        w[k] = w[k] + __uint_as_float((me | mi) & __float_as_uint(dw));
+                        w[k] = blend(me, __builtin_fminf(__builtin_fmaxf(w[k], 1e-06f), 10.0f), w[k]);
+                    }
                 }
             }
         } else {                                             // blitnet.py:218-231
+            LENS_REFRESH_MASKS();
             const float d = 0.5f - post;
-            const float de = d * eta, nde = d * (eta * -1.0f);
-            const bool b2 = post > 0.0f;
+            const uint32_t b2 = (post > 0.0f) ? 0xffffffffu : 0u;
+            const uint32_t de = __float_as_uint(d * eta) & b2, nde = __float_as_uint(d * (eta * -1.0f)) & b2;
 #pragma unroll
-            for (int n = 0; n < IN_PAD; ++n) {
-                if (pre[n] > 0.0f) {                         // wave-uniform
-                    const bool e = (eb[n >> 5] >> (n & 31)) & 1u, i = (ib[n >> 5] >> (n & 31)) & 1u;
-                    const float dw = e ? de : (i ? nde : 0.0f);
-                    w[n] = w[n] + (b2 ? dw : 0.0f);
+            for (int k4 = 0; k4 < HP; k4 += 4) {
+                if ((k4 & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+                const float4 p = *reinterpret_cast<const float4 *>(my_row + k4);
+                const float pr[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = k4 + c;
+                    const uint32_t b1 = (pr[c] > 0.0f) ? 0xffffffffu : 0u;          // (pre > 0)
+                    const uint32_t me = bit_mask(eb[k >> 5], k), mi = bit_mask(ib[k >> 5], k);
+                    w[k] = w[k] + __uint_as_float(((me & de) | (mi & nde)) & b1);
+                    w[k] = blend(me & b1, __builtin_fminf(__builtin_fmaxf(w[k], 1e-06f), 10.0f), w[k]);
                 }
             }
         }
+        if (t == 0) {
+            LENS_REFRESH_MASKS();
 #pragma unroll
-        for (int n = 0; n < IN_PAD; ++n) {                   // blitnet.py:234-235
-            const bool e = (eb[n >> 5] >> (n & 31)) & 1u, i = (ib[n >> 5] >> (n & 31)) & 1u;
-            const float ce = __builtin_fminf(__builtin_fmaxf(w[n], 1e-06f), 10.0f);
-            const float ci = __builtin_fminf(__builtin_fmaxf(w[n], -10.0f), -1e-06f);
-            w[n] = e ? ce : (i ? ci : w[n]);
+            for (int k = 0; k < HP; ++k)
+                w[k] = blend(bit_mask(eb[k >> 5], k), __builtin_fminf(__builtin_fmaxf(w[k], 1e-06f), 10.0f), w[k]);
         }
         if (a.have_rate && eip > 0.0f) {                     // blitnet.py:239-243
             thr = thr + eip * (lx - fr);
             thr = (thr < 0.0f) ? 0.0f : thr;
         }
-        if (eta != 0.0f) {                                   // blitnet.py:246-251
+        LENS_REFRESH_MASKS();
+        if (eta != 0.0f) {                                   // blitnet.py:246-251 (any(W) is implied: it adds 0 otherwise)
 #pragma unroll
-            for (int n = 0; n < IN_PAD; ++n) {
-                const float iw = (w[n] > 0.0f) ? 0.0f : w[n];
-                w[n] = w[n] + ((y * iw) * eta) * 50.0f;
+            for (int k = 0; k < HP; ++k) {
+                if ((k & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+                const float ci = __builtin_fminf(__builtin_fmaxf(w[k], -10.0f), -1e-06f);   // this step's inhibitory clamp
+                const float wn = blend(bit_mask(ib[k >> 5], k), ci, w[k]);
+                const float iw = __builtin_fminf(wn, 0.0f);  // inhW[inhW > 0] = 0
+                w[k] = wn + ((y * iw) * eta) * 50.0f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < HP; ++k) {
+                if ((k & 15) == 0) __builtin_amdgcn_sched_barrier(0);
+                const float ci = __builtin_fminf(__builtin_fmaxf(w[k], -10.0f), -1e-06f);
+                w[k] = blend(bit_mask(ib[k >> 5], k), ci, w[k]);
             }
         }
     }
+#undef LENS_REFRESH_MASKS
     if (valid) {
+        float *wr = a.w + (size_t)o * a.ldw + col0;
 #pragma unroll
-        for (int n = 0; n < IN_PAD; ++n)
-            if (n < a.n_in) a.w[(size_t)o * a.ldw + n] = w[n];
-        a.thr[o] = thr;
+        for (int k4 = 0; k4 < HP; k4 += 4)
+            *reinterpret_cast<float4 *>(wr + k4) = make_float4(w[k4], w[k4 + 1], w[k4 + 2], w[k4 + 3]);
+        if (h == 0) a.thr[o] = thr;
     }
 }
 
@@ -983,7 +1095,7 @@ int lens_layer_forward_clamped(const float *d_x, int S, int ldx, const float *d_
     return (int)hipGetLastError();
 }
 
-int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, const uint8_t *d_inh,
+int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, const uint8_t *d_inh, int ldm,
                      const float *d_fire_rate, int have_rate, const float *d_x_table, const float *d_mpre_table, int ldx,
                      const int32_t *d_order, const int32_t *d_force_idx, const float *d_eta_ip, const float *d_eta_stdp,
                      int n_out, int n_in, int T, void *stream)
@@ -992,22 +1104,24 @@ int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, co
         return LENS_ERR_NULL;
     const bool spk = d_force_idx != nullptr;
     if (spk && !d_mpre_table) return LENS_ERR_NULL;
-    if (n_out <= 0 || n_in <= 0 || T < 0 || ldw < n_in) return LENS_ERR_SIZE;
+    if (n_out <= 0 || n_in <= 0 || T < 0) return LENS_ERR_SIZE;
     const int pad = lens_train_in_pad(n_in);
     if (!pad) return LENS_ERR_UNSUPPORTED;
-    if (ldx < pad) return LENS_ERR_SIZE;
+    if (ldx < pad || ldw < pad || ldm < pad) return LENS_ERR_SIZE;
+    if ((ldw & 3) || ((uintptr_t)d_w & 15) || (ldx & 3) || ((uintptr_t)d_x_table & 15)) return LENS_ERR_ALIGN;
     if (T == 0) return LENS_OK;
-    TrainArgs a{d_w, ldw, d_thr, d_exc, d_inh, d_fire_rate, have_rate ? 1 : 0, d_x_table, d_mpre_table, ldx,
+    TrainArgs a{d_w, ldw, d_thr, d_exc, d_inh, ldm, d_fire_rate, have_rate ? 1 : 0, d_x_table, d_mpre_table, ldx,
                 d_order, d_force_idx, d_eta_ip, d_eta_stdp, n_out, n_in, T};
-    const dim3 grid((n_out + 63) / 64), block(64);
+    const dim3 block(64);
     hipStream_t st = (hipStream_t)stream;
-#define LENS_TRAIN_CASE(P)                                                                    \
-    case P:                                                                                   \
-        if (spk) hipLaunchKernelGGL((k_train_layer<P, true>), grid, block, 0, st, a);         \
-        else hipLaunchKernelGGL((k_train_layer<P, false>), grid, block, 0, st, a);            \
-        break;
+#define LENS_TRAIN_CASE(P, LPR)                                                                          \
+    case P: {                                                                                            \
+        const dim3 grid((n_out + 64 / LPR - 1) / (64 / LPR));                                            \
+        if (spk) hipLaunchKernelGGL((k_train_layer<P, LPR, true>), grid, block, 0, st, a);               \
+        else hipLaunchKernelGGL((k_train_layer<P, LPR, false>), grid, block, 0, st, a);                  \
+    } break;
     switch (pad) {
-        LENS_TRAIN_CASE(64) LENS_TRAIN_CASE(128) LENS_TRAIN_CASE(208) LENS_TRAIN_CASE(256)
+        LENS_TRAIN_CASE(64, 1) LENS_TRAIN_CASE(128, 1) LENS_TRAIN_CASE(208, 2) LENS_TRAIN_CASE(256, 2)
     }
 #undef LENS_TRAIN_CASE
     return (int)hipGetLastError();

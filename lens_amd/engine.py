@@ -266,19 +266,25 @@ def layer_forward_clamped(x_table, n_in, w, thr):
 
 
 def train_layer(w, thr, exc, inh, fire_rate, have_rate, x_table, order, eta_ip, eta_stdp, force_idx=None, mpre_table=None):
-    """T = len(order) training steps in place on the device tensors w [n_out,n_in] and thr [n_out]."""
+    """T = len(order) training steps in place on the device tensors w [n_out,n_in] and thr [n_out].
+    (The kernel works on zero-padded rows; padding / un-padding happens here, once per call.)"""
     for t, name in ((w, "w"), (thr, "thr"), (x_table, "x_table"), (order, "order")):
         _need_cuda(t, name)
     n_out, n_in = w.shape
-    assert w.is_contiguous() and thr.is_contiguous() and thr.numel() == n_out
+    assert thr.is_contiguous() and thr.numel() == n_out
     assert exc.dtype == torch.uint8 and inh.dtype == torch.uint8 and exc.shape == w.shape and inh.shape == w.shape
     assert order.dtype == torch.int32 and eta_ip.dtype == torch.float32 and eta_stdp.dtype == torch.float32
-    assert x_table.shape[1] >= train_in_pad(n_in)
+    ld = train_in_pad(n_in)
+    assert x_table.shape[1] >= ld
     if force_idx is not None:
         assert force_idx.dtype == torch.int32 and mpre_table is not None and mpre_table.shape == x_table.shape
-    st = _lib.lib().lens_train_layer(_ptr(w), n_in, _ptr(thr), _ptr(exc.contiguous()), _ptr(inh.contiguous()),
+    wp = pad_table(w, ld)
+    ep = torch.zeros((n_out, ld), dtype=torch.uint8, device=w.device); ep[:, :n_in] = exc
+    ip = torch.zeros((n_out, ld), dtype=torch.uint8, device=w.device); ip[:, :n_in] = inh
+    st = _lib.lib().lens_train_layer(_ptr(wp), ld, _ptr(thr), _ptr(ep), _ptr(ip), ld,
                                      _ptr(fire_rate), int(have_rate), _ptr(x_table), _ptr(mpre_table), x_table.shape[1],
                                      _ptr(order), _ptr(force_idx), _ptr(eta_ip), _ptr(eta_stdp),
                                      n_out, n_in, order.numel(), _stream())
     _lib.check(st, "lens_train_layer")
+    w.copy_(wp[:, :n_in])
     return w, thr

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 3
+#define LENS_AMD_ABI_VERSION 4
 
 enum {
     LENS_OK = 0,
@@ -198,6 +198,15 @@ int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, co
                      const float *d_fire_rate, int have_rate, const float *d_x_table, const float *d_mpre_table, int ldx,
                      const int32_t *d_order, const int32_t *d_force_idx, const float *d_eta_ip, const float *d_eta_stdp,
                      int n_out, int n_in, int T, void *stream);
+
+
+/*
+ * Sum-of-absolute-differences baseline (`--sad`).  Replaces `torch.cdist(a, b, 1)` of lens/src/sad.py:34-38
+ * on the raw frames: d_dist[i][j] = sum_k |query[i][k] - reference[j][k]|  (exact integer, stored as float32).
+ * d_query uint8 [Q][HW], d_reference uint8 [P][HW], HW % 16 == 0, 16-byte aligned, 8*HW <= 160 KiB (LDS tile).
+ */
+int lens_sad_matrix(const uint8_t *d_query, int Q, const uint8_t *d_reference, int P, int HW, float *d_dist, int ldo,
+                    void *stream);
 
 #ifdef __cplusplus
 }

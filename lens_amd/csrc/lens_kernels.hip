@@ -839,6 +839,49 @@ __global__ void __launch_bounds__(256) k_layer_forward_clamped(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------
+// f2. Sum-of-absolute-differences baseline (`--sad`): torch.cdist(query, reference, p=1) of lens/src/sad.py:38
+// on the raw uint8 frames.  A workgroup stages QT query frames in LDS; every lane owns one reference frame,
+// streams it 16 bytes at a time and accumulates |q - r| with v_sad_u8 (4 bytes per instruction) against the QT
+// broadcast query words.  Integer sums are exact; the result is converted to float32 once.
+// ------------------------------------------------------------------------------------------
+constexpr int SAD_QT = 8;
+
+__global__ void __launch_bounds__(256) k_sad_matrix(const uint8_t *__restrict__ q, int Q, const uint8_t *__restrict__ r,
+                                                    int P, int HW, float *__restrict__ out, int ldo)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int q0 = blockIdx.y * SAD_QT;
+    const int nq = (Q - q0) < SAD_QT ? (Q - q0) : SAD_QT;
+    const int hw16 = HW >> 4;                       // 16-byte words per frame (HW % 16 == 0 on this path)
+    uint4 *sq = reinterpret_cast<uint4 *>(smem);     // [SAD_QT][hw16]
+    for (int i = threadIdx.x; i < SAD_QT * hw16; i += blockDim.x) {
+        const int qi = i / hw16, k = i - qi * hw16;
+        sq[i] = (qi < nq) ? reinterpret_cast<const uint4 *>(q + (size_t)(q0 + qi) * HW)[k] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint4 *rr = reinterpret_cast<const uint4 *>(r + (size_t)p * HW);
+    uint32_t acc[SAD_QT];
+#pragma unroll
+    for (int qi = 0; qi < SAD_QT; ++qi) acc[qi] = 0u;
+    for (int k = 0; k < hw16; ++k) {
+        const uint4 rv = rr[k];
+#pragma unroll
+        for (int qi = 0; qi < SAD_QT; ++qi) {
+            const uint4 qv = sq[qi * hw16 + k];      // wave-uniform address: broadcast
+            acc[qi] = __builtin_amdgcn_sad_u8(qv.x, rv.x, acc[qi]);
+            acc[qi] = __builtin_amdgcn_sad_u8(qv.y, rv.y, acc[qi]);
+            acc[qi] = __builtin_amdgcn_sad_u8(qv.z, rv.z, acc[qi]);
+            acc[qi] = __builtin_amdgcn_sad_u8(qv.w, rv.w, acc[qi]);
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < SAD_QT; ++qi)
+        if (qi < nq) out[(size_t)(q0 + qi) * ldo + p] = (float)acc[qi];
+}
+
+// ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
 constexpr int LDS_BUDGET = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
@@ -1124,6 +1167,22 @@ int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, co
         LENS_TRAIN_CASE(64, 1) LENS_TRAIN_CASE(128, 1) LENS_TRAIN_CASE(208, 2) LENS_TRAIN_CASE(256, 2)
     }
 #undef LENS_TRAIN_CASE
+    return (int)hipGetLastError();
+}
+
+
+int lens_sad_matrix(const uint8_t *d_query, int Q, const uint8_t *d_reference, int P, int HW, float *d_dist, int ldo,
+                    void *stream)
+{
+    if (!d_query || !d_reference || !d_dist) return LENS_ERR_NULL;
+    if (Q < 0 || P < 0 || HW <= 0 || ldo < P) return LENS_ERR_SIZE;
+    if ((HW & 15) || ((uintptr_t)d_query & 15) || ((uintptr_t)d_reference & 15)) return LENS_ERR_ALIGN;
+    const size_t lds = (size_t)SAD_QT * HW;
+    if (lds > (size_t)LDS_BUDGET) return LENS_ERR_UNSUPPORTED;
+    if (Q == 0 || P == 0) return LENS_OK;
+    if (int e = set_lds(k_sad_matrix, lds)) return e;
+    hipLaunchKernelGGL(k_sad_matrix, dim3((P + 255) / 256, (Q + SAD_QT - 1) / SAD_QT), dim3(256), lds, (hipStream_t)stream,
+                       d_query, Q, d_reference, P, HW, d_dist, ldo);
     return (int)hipGetLastError();
 }
 

@@ -288,3 +288,24 @@ def train_layer(w, thr, exc, inh, fire_rate, have_rate, x_table, order, eta_ip, 
     _lib.check(st, "lens_train_layer")
     w.copy_(wp[:, :n_in])
     return w, thr
+
+
+# --------------------------------------------------------------------------------------------
+# SAD baseline
+# --------------------------------------------------------------------------------------------
+def sad_matrix(query, reference):
+    """L1 distance of every query frame to every reference frame (lens/src/sad.py:34-38).
+    uint8 device tensors [Q,H,W] / [P,H,W] -> float32 [Q,P] (exact integers)."""
+    _need_cuda(query, "query"); _need_cuda(reference, "reference")
+    assert query.dtype == torch.uint8 and reference.dtype == torch.uint8
+    q = query.reshape(query.shape[0], -1).contiguous()
+    r = reference.reshape(reference.shape[0], -1).contiguous()
+    HW = q.shape[1]
+    assert r.shape[1] == HW
+    pad = (-HW) % 16                                   # the kernel streams 16-byte words; zero padding adds |0-0|
+    if pad:
+        q = torch.nn.functional.pad(q, (0, pad)); r = torch.nn.functional.pad(r, (0, pad))
+    out = torch.empty((q.shape[0], r.shape[0]), dtype=torch.float32, device=q.device)
+    st = _lib.lib().lens_sad_matrix(_ptr(q), q.shape[0], _ptr(r), r.shape[0], q.shape[1], _ptr(out), r.shape[0], _stream())
+    _lib.check(st, "lens_sad_matrix")
+    return out

@@ -22,7 +22,7 @@ from . import blitnet as bn
 from ._lib import LensAmdError
 from .dataset import CustomImageDataset
 from .loggers import model_logger
-from .metrics import recallAtK
+from .metrics import recallAtK, createPR
 
 RECALL_N = [1, 5, 10, 15, 20, 25]
 
@@ -145,8 +145,22 @@ class LENS(nn.Module):
             plt.show()
             plt.close()
 
-        if self.PR_curve or self.sad:
-            raise NotImplementedError("--PR_curve / --sad are later rows of the build plan (SURVEY.md 8f-2/8f-3)")
+        # Same flag coupling as the reference (run_model.py:319-333): --PR_curve needs --matching (GTtol),
+        # --sad needs --PR_curve (lens_PR); the reference dies with a NameError there, here the message says why.
+        if self.PR_curve:
+            if not self.matching:
+                raise NameError("GTtol is not defined: --PR_curve needs --matching (as in the reference)")
+            LENS_P, LENS_R = createPR(dist_matrix_seq.T, GTtol.T, self.output_folder, matching="single", n_thresh=100)
+            lens_PR = {"Precision": LENS_P, "Recall": LENS_R}
+        if self.sad:
+            if not (self.matching and self.PR_curve):
+                raise NameError("lens_PR is not defined: --sad needs --matching and --PR_curve (as in the reference)")
+            from .sad import run_sad
+            from .plot_results import plot_PR, plot_recall
+            sad_PR, sad_Recall = run_sad(self.reference_dir, self.query_dir, GTtol, self.output_folder,
+                                         self.sequence_length, logger=model.logger)
+            plot_PR(lens_PR, sad_PR, self.output_folder)
+            plot_recall(R, sad_Recall, RECALL_N, self.output_folder)
 
         model.logger.info("")
         model.logger.info("Succesfully completed inferencing using LENS")

@@ -50,6 +50,8 @@ def lib():
         L.lens_oracle_layer_forward_clamped.argtypes = [c_p, c_p, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p]
         L.lens_oracle_train_layer.restype = None
         L.lens_oracle_train_layer.argtypes = [c_p] * 12 + [ctypes.c_int] * 4
+        L.lens_oracle_sad.restype = None
+        L.lens_oracle_sad.argtypes = [c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_int, c_p]
         _LIB = L
     return _LIB
 
@@ -242,3 +244,12 @@ def train_layer(w, thr, exc, inh, fire_rate, x_table, order, eta_ip, eta_stdp, f
                                   _p(fi) if spk else None, _p(pfr) if spk else None, _p(eip), _p(est),
                                   n_out, n_in, len(order), int(spk))
     return w, thr
+
+
+def sad_matrix(query, reference):
+    """lens/src/sad.py:34-38: L1 distance between every query and reference frame. uint8 [Q,...], [P,...] -> [Q,P]."""
+    q = np.ascontiguousarray(query, np.uint8).reshape(len(query), -1)
+    r = np.ascontiguousarray(reference, np.uint8).reshape(len(reference), -1)
+    d = np.zeros((len(q), len(r)), np.float32)
+    lib().lens_oracle_sad(_p(q), len(q), _p(r), len(r), q.shape[1], _p(d))
+    return d

@@ -234,3 +234,14 @@ def test_training_mode_init_and_preprocessing_match_the_reference():
     x = training_inputs(ds.frames(), 8)
     assert np.array_equal(x.numpy(), G["x_table"])
     assert np.array_equal(np.array([ds[i][1] for i in range(len(ds))]), G["labels"])
+
+
+def test_createPR_matches_the_reference():
+    """createPR('single', 100 thresholds) on the example run's matrix == lens/src/metrics.py::createPR output."""
+    from lens_amd.metrics import createPR
+    G = np.load(os.path.join(GOLDEN, "example.npz"))
+    PR = np.load(os.path.join(GOLDEN, "pr_sad.npz"))
+    P, R = createPR(G["S_carry"].T, G["GTtol"].astype(int).T, None, matching="single", n_thresh=100)
+    assert np.array_equal(np.array(P, np.float64), PR["lens_P"]) and np.array_equal(np.array(R, np.float64), PR["lens_R"])
+    P2, R2 = createPR(G["S_carry"], G["GTtol"].astype(int), None, matching="multi", n_thresh=7)
+    assert len(P2) == 8 and P2[0] == 1 and R2[0] == 0 and R2[-1] == 1.0

@@ -55,3 +55,24 @@ def test_cli_refuses_cpu_and_hw_modes():
         _run(["--matching", "--nocuda"])
     with pytest.raises(SystemExit):
         _run(["--event_driven"])
+
+
+def test_cli_pr_curve_and_sad_reproduce_reference_outputs():
+    """`--matching --PR_curve --sad`: LENS PR curve, SAD PR curve and SAD Recall@N equal what the reference's
+    createPR / run_sad produced on the same data, and the comparison artefacts are written."""
+    import json
+    PR = np.load(os.path.join(GOLDEN, "pr_sad.npz"))
+    R, folder = _run(["--matching", "--PR_curve", "--sad"])
+    lens = json.load(open(os.path.join(folder, "PR_curve_LENS.json")))
+    sad = json.load(open(os.path.join(folder, "PR_curve_SAD.json")))
+    assert np.array_equal(np.array(lens["Precision"], np.float64), PR["lens_P"])
+    assert np.array_equal(np.array(lens["Recall"], np.float64), PR["lens_R"])
+    assert np.array_equal(np.array(sad["Precision"], np.float64), PR["sad_P"])
+    assert np.array_equal(np.array(sad["Recall"], np.float64), PR["sad_R"])
+    rows = open(os.path.join(folder, "SAD_vs_LENS_RecallatN.csv")).read().strip().splitlines()
+    assert rows[0] == "N,SAD,LENS" and [float(x.split(",")[1]) for x in rows[1:]] == list(PR["sad_recall"])
+    for f in ("Precision_Recall_plot.pdf", "SAD_vs_LENS_RecallatN.pdf", "distance_matrix_SAD.pdf",
+              "similarity_matrix_LENS.pdf", "similarity_matrix_SAD.pdf"):
+        assert os.path.exists(os.path.join(folder, f)), f
+    with pytest.raises(NameError):
+        _run(["--PR_curve"])

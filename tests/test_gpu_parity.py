@@ -211,3 +211,23 @@ def test_accumulate_events_matches_oracle(O):
         accumulate_events(torch.tensor([[17, 1]], dtype=torch.int16).cuda(), torch.tensor([0, 1]).cuda(), 16)
     with pytest.raises(IndexError):
         O.accumulate_events(np.array([17], np.int16), np.array([1], np.int16), np.array([0, 1]), 16)
+
+
+def test_sad_matrix_matches_reference_and_oracle(O):
+    """lens_sad_matrix == torch.cdist(p=1) of the reference's run_sad on the bundled frames, and == the oracle
+    on ragged sizes (HW not a multiple of 16, Q not a multiple of the query tile)."""
+    import os
+    from PIL import Image
+    from helpers import ROOT, GOLDEN
+    from lens_amd.engine import sad_matrix
+    G = np.load(os.path.join(GOLDEN, "pr_sad.npz"))
+    base = os.path.join(ROOT, "lens/dataset/example/davis128")
+    q = np.stack([np.array(Image.open(os.path.join(base, "example-query", f))) for f in G["files_query"]])
+    r = np.stack([np.array(Image.open(os.path.join(base, "example-reference", f))) for f in G["files_reference"]])
+    d = sad_matrix(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()).cpu().numpy()
+    assert np.array_equal(d, G["sad_dist"])
+    rng = np.random.default_rng(9)
+    q2 = rng.integers(0, 256, size=(13, 7, 7)).astype(np.uint8)
+    r2 = rng.integers(0, 256, size=(301, 7, 7)).astype(np.uint8)
+    d2 = sad_matrix(torch.from_numpy(q2).cuda(), torch.from_numpy(r2).cuda()).cpu().numpy()
+    assert np.array_equal(d2, O.sad_matrix(q2, r2))

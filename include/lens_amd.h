@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 4
+#define LENS_AMD_ABI_VERSION 5
 
 enum {
     LENS_OK = 0,
@@ -207,6 +207,17 @@ int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, co
  */
 int lens_sad_matrix(const uint8_t *d_query, int Q, const uint8_t *d_reference, int P, int HW, float *d_dist, int ldo,
                     void *stream);
+
+
+/*
+ * DENSE variant of lens_output_counts on the f32 matrix cores (v_mfma_f32_32x32x2_f32), state reset per query.
+ * Same replacement (lens/run_model.py:145,155,239) and bit-identical results (the f32 MFMA is a k-ordered fmaf
+ * chain); kept as the measured "descriptor x database GEMM" comparison for DESIGN.md -- it is ~8x slower than the
+ * event-driven kernel because it cannot skip the ~97% zero spikes.
+ * d_featspk float [Q][T][ld_f] dense feature spike counts (lens_feature_events' optional output), F <= 256.
+ */
+int lens_output_counts_dense(const float *d_featspk, int Q, int T, int F, int ld_f, const float *d_w2t, int P, int ldw2,
+                             float *d_counts, int ldo, void *stream);
 
 #ifdef __cplusplus
 }

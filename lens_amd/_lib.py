@@ -36,6 +36,7 @@ SIGNATURES = {
     "lens_seqmatch": (_i, [_c_p, _i, _i, _i, _i, _c_p, _i, _c_p]),
     "lens_seqmatch_topk": (_i, [_c_p, _i, _i, _i, _i, _i, _i, _c_p, _c_p, _c_p]),
     "lens_topk_merge": (_i, [_c_p, _c_p, _i, _i, _i, _c_p, _c_p, _c_p]),
+    "lens_output_counts_dense": (_i, [_c_p, _i, _i, _i, _i, _c_p, _i, _i, _c_p, _i, _c_p]),
     "lens_sad_matrix": (_i, [_c_p, _i, _c_p, _i, _i, _c_p, _i, _c_p]),
     "lens_train_in_pad": (_i, [_i]),
     "lens_layer_forward_clamped": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _c_p]),
@@ -44,7 +45,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LensAmdError(RuntimeError):

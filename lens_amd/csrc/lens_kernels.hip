@@ -462,6 +462,75 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// a5-a6, DENSE variant: the "descriptor x database GEMM" on the f32 matrix cores, for comparison with the
+// event-driven kernel above.  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf
+// chain, so accumulating the dense [32 queries x F] spike tile of one time step against [F x 32 places]
+// gives exactly the oracle's ascending-f chain (zero spikes contribute fmaf(0, w, acc) == acc).
+//   workgroup = 4 wavefronts = 32 queries x 128 places; each wavefront keeps its 32 places' weights in
+//   registers (one VGPR per k-pair), the step's spike tile is staged in LDS, membrane potentials and counters
+//   of the 32x32 tile live in the 16 accumulator-layout registers; T steps inside the kernel.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KP>   // k-pairs held in registers: F <= 2 * KP
+__global__ void __launch_bounds__(256) k_output_counts_mfma(const float *__restrict__ spk, int Q, int T, int F, int lds_f,
+                                                            const float *__restrict__ w2t, int ldw, int P,
+                                                            float *__restrict__ counts, int ldo)
+{
+    constexpr int FP = 2 * KP + 1;                   // odd row stride: conflict-free column reads
+    __shared__ float sA[2][32 * FP];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.y * 32;
+    const int p0 = blockIdx.x * 128 + wave * 32;
+    const int col = lane & 31, hi = lane >> 5;
+    float b[KP];                                     // B[k = 2m + hi][j = col]
+#pragma unroll
+    for (int m = 0; m < KP; ++m) {
+        const int f = 2 * m + hi;
+        b[m] = (f < F) ? w2t[(size_t)f * ldw + p0 + col] : 0.0f;   // w2t is zero padded to ldw >= roundup(P, 256)
+    }
+    f32x16 v, cnt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { v[r] = 0.0f; cnt[r] = 0.0f; }
+
+    auto stage = [&](int t, int buf) {               // spike tile of step t: 32 queries x F -> LDS (zero padded)
+        for (int i = threadIdx.x; i < 32 * 2 * KP; i += blockDim.x) {
+            const int row = i / (2 * KP), f = i - row * (2 * KP);
+            const int q = q0 + row;
+            sA[buf][row * FP + f] = (q < Q && f < F) ? spk[((size_t)q * T + t) * lds_f + f] : 0.0f;
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) stage(t + 1, buf ^ 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float *arow = &sA[buf][col * FP + hi];  // A[i = col][k = 2m + hi]
+#pragma unroll
+        for (int m = 0; m < KP; ++m)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * m], b[m], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float vv = v[r];
+            cnt[r] += iaf_update(vv, acc[r]);
+            v[r] = vv;
+        }
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int p = p0 + col;
+        if (q < Q && p < P) counts[(size_t)q * ldo + p] = cnt[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // a7. sequence matcher, full matrix (query-major).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_seqmatch(const float *__restrict__ counts, int Ps, int ldo, int L,
@@ -1183,6 +1252,24 @@ int lens_sad_matrix(const uint8_t *d_query, int Q, const uint8_t *d_reference, i
     if (int e = set_lds(k_sad_matrix, lds)) return e;
     hipLaunchKernelGGL(k_sad_matrix, dim3((P + 255) / 256, (Q + SAD_QT - 1) / SAD_QT), dim3(256), lds, (hipStream_t)stream,
                        d_query, Q, d_reference, P, HW, d_dist, ldo);
+    return (int)hipGetLastError();
+}
+
+
+int lens_output_counts_dense(const float *d_featspk, int Q, int T, int F, int ld_f, const float *d_w2t, int P, int ldw2,
+                             float *d_counts, int ldo, void *stream)
+{
+    if (!d_featspk || !d_w2t || !d_counts) return LENS_ERR_NULL;
+    if (Q < 0 || T <= 0 || F <= 0 || ld_f < F || P <= 0 || ldw2 < P || ldo < P) return LENS_ERR_SIZE;
+    if (ldw2 & 255) return LENS_ERR_ALIGN;
+    if (F > 256) return LENS_ERR_UNSUPPORTED;
+    if (Q == 0) return LENS_OK;
+    const dim3 grid((P + 127) / 128, (Q + 31) / 32), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (F <= 64) hipLaunchKernelGGL(k_output_counts_mfma<32>, grid, block, 0, st, d_featspk, Q, T, F, ld_f, d_w2t, ldw2, P, d_counts, ldo);
+    else if (F <= 128) hipLaunchKernelGGL(k_output_counts_mfma<64>, grid, block, 0, st, d_featspk, Q, T, F, ld_f, d_w2t, ldw2, P, d_counts, ldo);
+    else if (F <= 200) hipLaunchKernelGGL(k_output_counts_mfma<100>, grid, block, 0, st, d_featspk, Q, T, F, ld_f, d_w2t, ldw2, P, d_counts, ldo);
+    else hipLaunchKernelGGL(k_output_counts_mfma<128>, grid, block, 0, st, d_featspk, Q, T, F, ld_f, d_w2t, ldw2, P, d_counts, ldo);
     return (int)hipGetLastError();
 }
 

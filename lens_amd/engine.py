@@ -167,6 +167,16 @@ class LensEngine:
         _lib.check(st, "lens_output_counts")
         return out
 
+    def forward_counts_dense(self, frames):
+        """Same result as forward_counts(carry=False), computed with the dense f32-MFMA kernel (comparison path)."""
+        Q = frames.shape[0]
+        spk = self.feature_events(frames, carry=False, want_spikes=True)
+        out = torch.empty((Q, self.P), dtype=torch.float32, device=self.device)
+        st = _lib.lib().lens_output_counts_dense(_ptr(spk), Q, self.T, self.F, self.F, _ptr(self.w2t), self.P, self.ldw2,
+                                                 _ptr(out), self.P, _stream())
+        _lib.check(st, "lens_output_counts_dense")
+        return out
+
     def forward_counts(self, frames, carry=False, n_groups=0, check_status=True):
         """The query loop of LENS.evaluate (lens/run_model.py:229-246) for a batch of frames:
         uint8 [Q,H,W] -> similarity-matrix rows float32 [Q,P].  carry=True integrates the queries

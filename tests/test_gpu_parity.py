@@ -231,3 +231,22 @@ def test_sad_matrix_matches_reference_and_oracle(O):
     r2 = rng.integers(0, 256, size=(301, 7, 7)).astype(np.uint8)
     d2 = sad_matrix(torch.from_numpy(q2).cuda(), torch.from_numpy(r2).cuda()).cpu().numpy()
     assert np.array_equal(d2, O.sad_matrix(q2, r2))
+
+
+@pytest.mark.parametrize("P,Q", [(1000, 40), (130, 33)])
+def test_dense_mfma_variant_is_bit_identical(P, Q, O):
+    """The f32-MFMA dense kernel (k-ordered fmaf chain in hardware) == the event-driven kernel == the oracle."""
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    w2 = synthetic_database(w2p, P).numpy()
+    frames = synthetic_frames(Q, 128, seed=17)
+    eng = _engine(w1, w2, 128, 10)
+    a = eng.forward_counts(frames.cuda(), carry=False).cpu().numpy()
+    b = eng.forward_counts_dense(frames.cuda()).cpu().numpy()
+    assert np.array_equal(a, b)
+    ref = O.forward(frames.numpy(), 10, O.rand_U(250, 128 * 128), w1, w2, carry=False, skip_zero=True)
+    assert np.array_equal(b, ref) and b.sum() > 0
+    c, fr, w1b, w2b, gt, G = load_config("sunset")          # F = 63 (k-pair padding), P = 641
+    eng2 = _engine(w1b, w2b, c["roi"], c["dims"])
+    out = eng2.forward_counts_dense(torch.from_numpy(fr[:50]).cuda()).cpu().numpy()
+    assert np.array_equal(out.astype(np.int16), G["out_reset"][:50])

@@ -34,11 +34,14 @@ def gather_topk(idx, val, group=None):
     Works with any backend (RCCL on device tensors; gloo on CPU tensors in the tests)."""
     world = dist.get_world_size(group)
     q, k = idx.shape
+    dev = idx.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":      # test transport: stage through the host
+        idx, val = idx.cpu(), val.cpu()
     idx_all = torch.empty((world * q, k), dtype=idx.dtype, device=idx.device)   # concatenation along dim 0
     val_all = torch.empty((world * q, k), dtype=val.dtype, device=val.device)
     dist.all_gather_into_tensor(idx_all, idx.contiguous(), group=group)
     dist.all_gather_into_tensor(val_all, val.contiguous(), group=group)
-    return idx_all.view(world, q, k), val_all.view(world, q, k)
+    return idx_all.view(world, q, k).to(dev), val_all.view(world, q, k).to(dev)
 
 
 class ShardedMatcher:

@@ -47,6 +47,7 @@ __device__ __forceinline__ float iaf_update(float &v, float cur)
     return s;
 }
 
+// (iaf_update_fast below = the same update with the clip of iaf_clip.)
 // The lower clip v = relu(vm + 1) - 1 in two full-rate instructions (v_max_f32 is half rate on gfx950):
 //   h = clamp(fma(vm, 0.5, 0.5), 0, 1) == 0.5 * relu(fl(vm + 1))   exactly (scaling by 0.5 commutes with the
 //       rounding; the upper clamp never binds because vm < 1 here, so fl(vm + 1) <= 2)
@@ -56,6 +57,16 @@ __device__ __forceinline__ float iaf_clip(float vm)
     float h;
     asm("v_fma_f32 %0, %1, 0.5, 0.5 clamp" : "=v"(h) : "v"(vm));
     return __builtin_fmaf(h, 2.0f, -1.0f);
+}
+
+// iaf_update with the two-instruction clip (valid because vm - s < 1 always)
+__device__ __forceinline__ float iaf_update_fast(float &v, float cur)
+{
+    float vm = v + cur;
+    const float s = __builtin_floorf(__builtin_fmaxf(vm, 0.0f));
+    vm = vm - s;
+    v = iaf_clip(vm);
+    return s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -192,20 +203,27 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
             px[i] = (selr[i] >= 0) ? (uint32_t)a.frames[(size_t)q * a.HW + selr[i]] : 0u;
         uint32_t *ev = a.events + (size_t)q * a.cap;
         uint32_t count = 0;
+        auto load_codes = [&](int t, uint32_t (&code)[NPL]) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                if constexpr (USE_LDS) {
+                    code[i] = s_codes[t * NP + i * 64 + lane];
+                } else {
+                    const int n = i * 64 + lane;
+                    code[i] = (n < a.N) ? (uint32_t)a.codes[(size_t)t * a.N + n] : 255u;
+                }
+            }
+        };
+        uint32_t code[NPL], code_next[NPL];
+        load_codes(0, code);
         for (int t = 0; t < a.T; ++t) {
+            if (t + 1 < a.T) load_codes(t + 1, code_next);   // next step's thresholds: off the dependent chain
             float acc[FPL];
 #pragma unroll
             for (int j = 0; j < FPL; ++j) acc[j] = 0.0f;
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
-                uint32_t code;
-                if constexpr (USE_LDS) {
-                    code = s_codes[t * NP + i * 64 + lane];
-                } else {
-                    const int n = i * 64 + lane;
-                    code = (n < a.N) ? (uint32_t)a.codes[(size_t)t * a.N + n] : 255u;
-                }
-                uint64_t m = __ballot(px[i] >= code);
+                uint64_t m = __ballot(px[i] >= code[i]);
                 while (m) {   // active inputs in ascending n (wave-uniform loop)
                     const int n = i * 64 + __builtin_ctzll(m);
                     m &= m - 1;
@@ -222,12 +240,14 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                     }
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) code[i] = code_next[i];
             float sp[FPL];
             uint64_t sm[FPL];
             uint32_t total = 0;
 #pragma unroll
             for (int j = 0; j < FPL; ++j) {
-                sp[j] = iaf_update(v[j], acc[j]);
+                sp[j] = iaf_update_fast(v[j], acc[j]);
                 sm[j] = __ballot(sp[j] > 0.0f);
                 total += (uint32_t)__builtin_popcountll(sm[j]);
             }

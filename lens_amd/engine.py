@@ -119,6 +119,9 @@ class LensEngine:
         w2t[:, :self.P] = w2.t().to(dev)
         self.w2t = w2t
         self.cap = int(_lib.lib().lens_event_capacity_words(self.T, self.F))
+        # the spike-stream workspace is sized for the worst case (every feature spikes every step):
+        # keep it below ~4 GB by limiting the queries processed per launch
+        self.max_batch = max(1, min(self.max_batch, (4 << 30) // (4 * self.cap)))
         self.ev_scale = int(_lib.lib().lens_event_scale(self.F))
         self.n_streams = 1
         self.reset_state()

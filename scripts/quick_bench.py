@@ -12,12 +12,21 @@ ap.add_argument("--places", type=int, default=1000)
 ap.add_argument("--queries", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--groups", type=int, default=0)
+ap.add_argument("--real", action="store_true", help="bundled 80x80 example query frames tiled to --queries (real spike density)")
 ap.add_argument("--dense", action="store_true", help="also time the dense f32-MFMA variant of the output layer")
 a = ap.parse_args()
 w1, w2p = pretrained_example()
 w2 = synthetic_database(w2p, a.places)
-frames = synthetic_frames(a.queries, 128).cuda()
-eng = LensEngine(w1, w2, 128, 10, 250, max_batch=a.queries)
+if a.real:
+    from helpers import load_config
+    c, fr, *_ = load_config("example")
+    reps = (a.queries + len(fr) - 1) // len(fr)
+    frames = torch.from_numpy(fr).repeat(reps, 1, 1)[:a.queries].contiguous().cuda()
+    roi = 80
+else:
+    frames = synthetic_frames(a.queries, 128).cuda()
+    roi = 128
+eng = LensEngine(w1, w2, roi, 10, 250, max_batch=a.queries)
 def ev(): return torch.cuda.Event(enable_timing=True)
 for it in range(a.iters):
     e = [ev() for _ in range(4)]

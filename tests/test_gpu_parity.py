@@ -250,3 +250,12 @@ def test_dense_mfma_variant_is_bit_identical(P, Q, O):
     eng2 = _engine(w1b, w2b, c["roi"], c["dims"])
     out = eng2.forward_counts_dense(torch.from_numpy(fr[:50]).cuda()).cpu().numpy()
     assert np.array_equal(out.astype(np.int16), G["out_reset"][:50])
+
+
+@pytest.mark.parametrize("mode", ["carry", "reset"])
+def test_batch_chunking_is_transparent(mode, O):
+    """Queries processed in several launches (max_batch < Q) give the same counts, in both state modes."""
+    c, frames, w1, w2, gt, G = load_config("example")
+    eng = _engine(w1, w2, c["roi"], c["dims"], max_batch=7)
+    out = eng.forward_counts(torch.from_numpy(frames[:31]).cuda(), carry=(mode == "carry")).cpu().numpy()
+    assert np.array_equal(out.astype(np.int16), G[f"out_{mode}"][:31])

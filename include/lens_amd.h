@@ -76,7 +76,7 @@ int lens_accumulate_events(const int16_t *d_xy, const int64_t *d_frame_off, int 
  */
 int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_codes);
 
-/* Words of `events` a query needs in the worst case: roundup16(2 * T * max(F, 1)). */
+/* Words of `events` a query needs in the worst case: 2 * T * max(F, 1) rounded up to whole 32-word chunks. */
 size_t lens_event_capacity_words(int T, int F);
 
 /* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F) can consume
@@ -98,10 +98,10 @@ int lens_event_scale(int F);
  * at the end.  carry == 0: state is zeroed before every query, d_vfeat is not touched (may be
  * NULL), n_streams only sets the parallelism (<= 0: one stream per query).
  *
- * Output stream of query q, d_events + q*cap_words, d_nwords[q] words (a multiple of 16):
+ * Output stream of query q, d_events + q*cap_words, d_nwords[q] words (a multiple of 32):
  *   per time step, the spiking features in ascending f as two-word events
  *       word 0 = f * ev_scale,  word 1 = float(spike count), sign bit set on the LAST event of the step
- *   (a step without spikes is one event {0, -0.0f}); null events {0, +0.0f} pad to a multiple of 16 words.
+ *   (a step without spikes is one event {0, -0.0f}); null events {0, +0.0f} pad to a multiple of 32 words.
  * d_featspk (optional, NULL to skip): float [Q][T][F] dense spike counts.
  * Limits: N <= 1024, F <= 2048, cap_words >= lens_event_capacity_words(T, F), ev_scale * F < 2^31.
  */

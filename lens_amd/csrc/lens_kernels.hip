@@ -28,6 +28,12 @@ namespace {
 //   word 1: float(spike count) with the sign bit set on the LAST event of a time step (counts are >= 0, the
 //           consumer uses |word 1|).  A step without spikes is one event {0, -0.0f}; {0, +0.0f} pads.
 constexpr uint32_t EV_LAST = 0x80000000u;
+// Events per chunk of the output kernel = events per scalar prefetch (two s_load_dwordx16).  The scalar
+// load of the next chunk is the only memory latency on the critical path (~900 cycles from L2 / Infinity
+// Cache, one prefetch in flight per wavefront because LDS and scalar memory share the LGKM counter); 16
+// events of compute per exposure keep four wavefronts per SIMD busy (8 events did not: DESIGN.md section 5).
+constexpr int EV_CHUNK = 16;
+constexpr int EV_WORDS = 2 * EV_CHUNK;
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 {
@@ -277,8 +283,8 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                 count += total;
             }
         }
-        // count is in events (2 words each); pad with null events to a whole 16-word chunk
-        const uint32_t pad = (8u - (count & 7u)) & 7u;
+        // count is in events (2 words each); pad with null events to a whole chunk of EV_CHUNK events
+        const uint32_t pad = ((uint32_t)EV_CHUNK - (count & (EV_CHUNK - 1))) & (EV_CHUNK - 1);
         if ((uint32_t)lane < pad) reinterpret_cast<uint2 *>(ev)[count + lane] = make_uint2(0u, 0u);
         if (lane == 0) a.nwords[q] = 2u * (count + pad);
     }
@@ -319,17 +325,17 @@ __device__ __forceinline__ void vec_unpack(const typename VecT<PPL>::type &x, fl
     else { o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; }
 }
 
-// Weight reads for one chunk of the spike stream (8 events), issued together.  They are completed
-// (weights_token) before the NEXT chunk's scalar load is put in flight: LDS and scalar memory share the
-// LGKM counter and scalar loads return out of order, so an LDS wait with a scalar load outstanding would
-// degenerate to lgkmcnt(0) and wait for the prefetch too.
+// Weight reads for one chunk of the spike stream, issued together.  They are completed (weights_token)
+// before the NEXT chunk's scalar load is put in flight: LDS and scalar memory share the LGKM counter and
+// scalar loads return out of order, so an LDS wait with a scalar load outstanding would degenerate to
+// lgkmcnt(0) and wait for the prefetch too.
 template <int PPL, bool W_LDS>
-__device__ __forceinline__ void load_weights(const uint32_t (&e)[16], const unsigned char *smem, const float *w2t,
-                                             int ldw, int pl, uint32_t lane_off, float (&w)[8][PPL])
+__device__ __forceinline__ void load_weights(const uint32_t (&e)[EV_WORDS], const unsigned char *smem, const float *w2t,
+                                             int ldw, int pl, uint32_t lane_off, float (&w)[EV_CHUNK][PPL])
 {
     using vec_t = typename VecT<PPL>::type;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < EV_CHUNK; ++i) {
         vec_t wv;
         if constexpr (W_LDS) {
             wv = *reinterpret_cast<const vec_t *>(smem + (e[2 * i] + lane_off));
@@ -345,38 +351,36 @@ __device__ __forceinline__ void load_weights(const uint32_t (&e)[16], const unsi
 // Adding it to the next chunk's offset makes the next scalar load wait until the LDS reads have
 // completed (the asm needs the weights in registers => lgkmcnt(0) before it).
 template <int PPL>
-__device__ __forceinline__ uint32_t weights_token(const float (&w)[8][PPL])
+__device__ __forceinline__ uint32_t weights_token(const float (&w)[EV_CHUNK][PPL])
 {
-    uint32_t t0, t1 = 0;
-    if constexpr (PPL == 1) {
-        asm("s_mov_b32 %0, 0" : "=s"(t0) : "v"(w[0][0]), "v"(w[1][0]), "v"(w[2][0]), "v"(w[3][0]),
-                                           "v"(w[4][0]), "v"(w[5][0]), "v"(w[6][0]), "v"(w[7][0]));
-    } else if constexpr (PPL == 2) {
-        asm("s_mov_b32 %0, 0" : "=s"(t0) : "v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]),
-                                           "v"(w[2][0]), "v"(w[2][1]), "v"(w[3][0]), "v"(w[3][1]),
-                                           "v"(w[4][0]), "v"(w[4][1]), "v"(w[5][0]), "v"(w[5][1]),
-                                           "v"(w[6][0]), "v"(w[6][1]), "v"(w[7][0]), "v"(w[7][1]));
-    } else {
-        asm("s_mov_b32 %0, 0" : "=s"(t0) : "v"(w[0][0]), "v"(w[0][1]), "v"(w[0][2]), "v"(w[0][3]),
-                                           "v"(w[1][0]), "v"(w[1][1]), "v"(w[1][2]), "v"(w[1][3]),
-                                           "v"(w[2][0]), "v"(w[2][1]), "v"(w[2][2]), "v"(w[2][3]),
-                                           "v"(w[3][0]), "v"(w[3][1]), "v"(w[3][2]), "v"(w[3][3]));
-        asm("s_mov_b32 %0, 0" : "=s"(t1) : "v"(w[4][0]), "v"(w[4][1]), "v"(w[4][2]), "v"(w[4][3]),
-                                           "v"(w[5][0]), "v"(w[5][1]), "v"(w[5][2]), "v"(w[5][3]),
-                                           "v"(w[6][0]), "v"(w[6][1]), "v"(w[6][2]), "v"(w[6][3]),
-                                           "v"(w[7][0]), "v"(w[7][1]), "v"(w[7][2]), "v"(w[7][3]));
+    uint32_t tok = 0;
+#pragma unroll
+    for (int i = 0; i < EV_CHUNK; i += 4) {       // 4 events per asm statement (<= 16 inputs, limit is 30)
+        uint32_t t;
+        if constexpr (PPL == 1) {
+            asm("s_mov_b32 %0, 0" : "=s"(t) : "v"(w[i][0]), "v"(w[i + 1][0]), "v"(w[i + 2][0]), "v"(w[i + 3][0]));
+        } else if constexpr (PPL == 2) {
+            asm("s_mov_b32 %0, 0" : "=s"(t) : "v"(w[i][0]), "v"(w[i][1]), "v"(w[i + 1][0]), "v"(w[i + 1][1]),
+                                              "v"(w[i + 2][0]), "v"(w[i + 2][1]), "v"(w[i + 3][0]), "v"(w[i + 3][1]));
+        } else {
+            asm("s_mov_b32 %0, 0" : "=s"(t) : "v"(w[i][0]), "v"(w[i][1]), "v"(w[i][2]), "v"(w[i][3]),
+                                              "v"(w[i + 1][0]), "v"(w[i + 1][1]), "v"(w[i + 1][2]), "v"(w[i + 1][3]),
+                                              "v"(w[i + 2][0]), "v"(w[i + 2][1]), "v"(w[i + 2][2]), "v"(w[i + 2][3]),
+                                              "v"(w[i + 3][0]), "v"(w[i + 3][1]), "v"(w[i + 3][2]), "v"(w[i + 3][3]));
+        }
+        tok |= t;
     }
-    return t0 | t1;
+    return tok;
 }
 
-// The 8 events of a chunk against this lane's PPL places.  All control flow is wave-uniform (the
+// The events of a chunk against this lane's PPL places.  All control flow is wave-uniform (the
 // event words live in SGPRs); no memory instruction in here.
 template <int PPL>
-__device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[16], const float (&w)[8][PPL], float (&v)[PPL],
-                                                float (&cnt)[PPL], float (&acc)[PPL])
+__device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], const float (&w)[EV_CHUNK][PPL],
+                                                float (&v)[PPL], float (&cnt)[PPL], float (&acc)[PPL])
 {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < EV_CHUNK; ++i) {
         const float sv = __builtin_fabsf(__uint_as_float(e[2 * i + 1]));
 #pragma unroll
         for (int k = 0; k < PPL; ++k) acc[k] = __builtin_fmaf(sv, w[i][k], acc[k]);
@@ -445,27 +449,27 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
             acc[k] = 0.0f;
         }
         const uint32_t *ev = a.events + (size_t)q * a.cap;
-        const int nch = (int)(a.nwords[q] >> 4);
-        // 8 events (16 words) per scalar load, two SGPR buffers in ping-pong.  Per chunk: weight reads ->
-        // lgkmcnt(0) -> scalar load of the next chunk -> VALU/SALU-only integration while it is in flight.
-        uint32_t ea[16], eb[16];
-        float w[8][PPL];
+        const int nch = (int)(a.nwords[q] / EV_WORDS);
+        // One chunk (EV_CHUNK events) per scalar prefetch, two SGPR buffers in ping-pong.  Per chunk: weight
+        // reads -> lgkmcnt(0) -> scalar load of the next chunk -> VALU/SALU-only integration while it is in flight.
+        uint32_t ea[EV_WORDS], eb[EV_WORDS];
+        float w[EV_CHUNK][PPL];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ea[i] = ev[i];
+        for (int i = 0; i < EV_WORDS; ++i) ea[i] = ev[i];
         for (int c = 0; c < nch; c += 2) {
             load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, w);
-            const uint32_t *nxt = ev + (size_t)(c + 1) * 16 + weights_token<PPL>(w);
+            const uint32_t *nxt = ev + (size_t)(c + 1) * EV_WORDS + weights_token<PPL>(w);
             if (c + 1 < nch) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) eb[i] = nxt[i];
+                for (int i = 0; i < EV_WORDS; ++i) eb[i] = nxt[i];
             }
             integrate_chunk<PPL>(ea, w, v, cnt, acc);
             if (c + 1 >= nch) break;
             load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
-            nxt = ev + (size_t)(c + 2) * 16 + weights_token<PPL>(w);
+            nxt = ev + (size_t)(c + 2) * EV_WORDS + weights_token<PPL>(w);
             if (c + 2 < nch) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) ea[i] = nxt[i];
+                for (int i = 0; i < EV_WORDS; ++i) ea[i] = nxt[i];
             }
             integrate_chunk<PPL>(eb, w, v, cnt, acc);
         }
@@ -1082,7 +1086,7 @@ int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_co
 size_t lens_event_capacity_words(int T, int F)
 {
     const size_t per_step = (size_t)(F > 1 ? F : 1);   // events per step, 2 words each
-    return ((2 * (size_t)(T > 0 ? T : 0) * per_step) + 15) & ~(size_t)15;
+    return ((2 * (size_t)(T > 0 ? T : 0) * per_step) + (EV_WORDS - 1)) & ~(size_t)(EV_WORDS - 1);
 }
 
 // places per lane of the output kernel for a given F: the widest tile whose W2^T columns fit in LDS
@@ -1108,7 +1112,7 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW, const int32_t *d
     if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_events || !d_nwords) return LENS_ERR_NULL;
     if (carry && !d_vfeat) return LENS_ERR_NULL;
     if (Q < 0 || HW <= 0 || N <= 0 || T <= 0 || F <= 0 || ldw1 < F) return LENS_ERR_SIZE;
-    if ((size_t)cap_words < lens_event_capacity_words(T, F) || (cap_words & 15)) return LENS_ERR_SIZE;
+    if ((size_t)cap_words < lens_event_capacity_words(T, F) || (cap_words & (EV_WORDS - 1))) return LENS_ERR_SIZE;
     if (N > 1024 || F > 2048) return LENS_ERR_UNSUPPORTED;
     if (ev_scale < 1 || (long long)ev_scale * F > 0x7fffffffLL) return LENS_ERR_SIZE;
     if (Q == 0) return LENS_OK;

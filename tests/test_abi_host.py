@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 
 
 def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
-    assert L.lens_feature_events(None, 1, 1, None, 1, None, 1, None, 1, 1, None, 1, 0, None, 16, None, 1, None, None) == -1
+    assert L.lens_feature_events(None, 1, 1, None, 1, None, 1, None, 1, 1, None, 1, 0, None, 32, None, 1, None, None) == -1
     assert L.lens_output_counts(None, 16, None, 1, None, 1, 1, 256, None, 1, 1, 0, None, 1, None) == -1
     assert L.lens_seqmatch_topk(None, 1, 1, 1, 1, 1, 0, None, None, None) == -1
     assert L.lens_accumulate_events(None, None, 0, 8, None, None, None) == -1
@@ -45,7 +45,7 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     assert L.lens_output_counts(p, 16, p, 1, p, 4, 10, 100, None, 10, 1, 0, p, 10, None) == -4   # ldw2 % 256
     assert L.lens_amd_strerror(-2).decode().startswith("a size")
     assert L.lens_event_capacity_words(250, 200) == 100000
-    assert L.lens_event_capacity_words(3, 0) == 16
+    assert L.lens_event_capacity_words(3, 0) == 32
     assert L.lens_event_scale(200) == 512 and L.lens_event_scale(63) == 1024 and L.lens_event_scale(5000) == 1
 
 

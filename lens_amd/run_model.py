@@ -103,7 +103,10 @@ class LENS(nn.Module):
         import matplotlib.pyplot as plt
         from .engine import seqmatch
 
-        frames = test_loader.frames() if hasattr(test_loader, "frames") else test_loader
+        if hasattr(test_loader, "frames_to_device"):
+            frames = test_loader.frames_to_device(self.device)
+        else:
+            frames = test_loader.frames() if hasattr(test_loader, "frames") else test_loader
         counts = self.similarity_rows(frames)
         out = counts.cpu().numpy().astype(np.float64)
         out = np.reshape(out, (model.query_places, model.reference_places))

@@ -169,6 +169,7 @@ def test_dataset_loader_and_metrics_mirror():
     ds = CustomImageDataset(os.path.join(ROOT, "lens/dataset/example-query.csv"),
                             os.path.join(ROOT, "lens/dataset/example/davis128/example-query"), skip=3, max_samples=7)
     assert len(ds) == 7 and np.array_equal(ds.frames().numpy(), frames[::3][:7])
+    assert np.array_equal(ds.frames(workers=1).numpy(), ds.frames(workers=4).numpy())
     assert ds[2][1] == 6
     with pytest.raises(FileNotFoundError):
         CustomImageDataset(os.path.join(ROOT, "lens/dataset/example-query.csv"), "/nonexistent")[0]

@@ -598,34 +598,31 @@ __device__ __forceinline__ void wave_insert(float &ln, int &lj, float cn, int cj
     else if (lane == pos) { ln = cn; lj = cj; }
 }
 
-// a7 + top-K.  One workgroup per query column; wavefronts scan 64-place chunks from the highest
-// place index down (so that later ties never displace earlier ones), keep a private top-64 and
-// merge through LDS.
+// a7 + top-K.  One WAVEFRONT per query column (four per workgroup, no cross-wave merge): it scans 64-place
+// chunks from the highest place index down (so that later ties never displace earlier ones), U chunks of loads
+// in flight, and keeps a lane-distributed sorted top-64 list.
 // LT = compile-time sequence length (0: use the run-time L), so that the L loads of a chunk are independent.
 template <int LT>
 __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__ counts, int ldo, int n_places,
-                                                       int Lrt, int K, int place_offset,
+                                                       int Lrt, int K, int place_offset, int n_queries,
                                                        int32_t *__restrict__ tk_idx, float *__restrict__ tk_val)
 {
-    __shared__ float s_n[4][64];
-    __shared__ int s_j[4][64];
     const int L = LT ? LT : Lrt;
-    const int i = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nw = blockDim.x >> 6;
+    const int i = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (i >= n_queries) return;
     float ln = -1.0f;   // empty entry: loses against every real candidate (n >= 0)
     int lj = -1;
     float tn = -1.0f;   // current K-th best
     int tj = -1;
     const int nchunks = (n_places + 63) >> 6;
     constexpr int U = 8;   // chunks (loads) in flight per wavefront: the scan is HBM-bound, not latency-bound
-    for (int c0 = wave; c0 < nchunks; c0 += nw * U) {
+    for (int c0 = 0; c0 < nchunks; c0 += U) {
         float n[U];
         int j[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int c = c0 + u * nw;
+            const int c = c0 + u;
             j[u] = (c < nchunks) ? n_places - 1 - (c * 64 + lane) : -1;
             const int jc = j[u] < 0 ? 0 : j[u];   // unconditional loads (clamped index), masked by j[u] below
             n[u] = 0.0f;
@@ -649,22 +646,6 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
                     tn = bcast(ln, K - 1);
                     tj = bcast(lj, K - 1);
                 }
-            }
-        }
-    }
-    s_n[wave][lane] = ln;
-    s_j[wave][lane] = lj;
-    __syncthreads();
-    if (wave != 0) return;
-    for (int w = 1; w < nw; ++w) {
-        for (int e = 0; e < K; ++e) {
-            const float cn = s_n[w][e];
-            const int cj = s_j[w][e];
-            if (cj < 0) break;
-            if (beats(cn, cj, tn, tj)) {
-                wave_insert(ln, lj, cn, cj, lane);
-                tn = bcast(ln, K - 1);
-                tj = bcast(lj, K - 1);
             }
         }
     }
@@ -1188,15 +1169,19 @@ int lens_seqmatch_topk(const float *d_counts, int Q, int ldo, int n_places, int 
 {
     if (!d_counts || !d_topk_idx || !d_topk_val) return LENS_ERR_NULL;
     if (L < 1 || Q < L || n_places < 1 || n_places + L - 1 > ldo || K < 1 || K > 64) return LENS_ERR_SIZE;
-    const dim3 grid(Q - L + 1), block(256);
+    const int nq = Q - L + 1;
+    const dim3 grid((nq + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
+#define LENS_TOPK_CASE(LT) hipLaunchKernelGGL(k_seqmatch_topk<LT>, grid, block, 0, st, d_counts, ldo, n_places, L, K, \
+                                              place_offset, nq, d_topk_idx, d_topk_val)
     switch (L) {
-    case 1: hipLaunchKernelGGL(k_seqmatch_topk<1>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
-    case 2: hipLaunchKernelGGL(k_seqmatch_topk<2>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
-    case 3: hipLaunchKernelGGL(k_seqmatch_topk<3>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
-    case 4: hipLaunchKernelGGL(k_seqmatch_topk<4>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
-    default: hipLaunchKernelGGL(k_seqmatch_topk<0>, grid, block, 0, st, d_counts, ldo, n_places, L, K, place_offset, d_topk_idx, d_topk_val); break;
+    case 1: LENS_TOPK_CASE(1); break;
+    case 2: LENS_TOPK_CASE(2); break;
+    case 3: LENS_TOPK_CASE(3); break;
+    case 4: LENS_TOPK_CASE(4); break;
+    default: LENS_TOPK_CASE(0); break;
     }
+#undef LENS_TOPK_CASE
     return (int)hipGetLastError();
 }
 

@@ -171,13 +171,35 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
     uint8_t *s_codes = smem;
     float *s_w = reinterpret_cast<float *>(smem + ((a.T * NP + 15) & ~15));
     if constexpr (USE_LDS) {
-        for (int i = threadIdx.x; i < a.T * NP; i += blockDim.x) {
-            const int t = i / NP, n = i - t * NP;
-            s_codes[i] = (n < a.N) ? a.codes[(size_t)t * a.N + n] : (uint8_t)255;
+        // stage the threshold codes [T][N] -> [T][NP] (padding 255 never fires) and W1^T [N][ldw] -> [N][FP]
+        // (padding 0); 4 elements per thread and iteration when the row lengths allow aligned vector loads
+        if ((a.N & 3) == 0 && (((uintptr_t)a.codes) & 3) == 0) {
+            const int n4 = a.N >> 2;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_codes);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.codes);
+            for (int i = threadIdx.x; i < a.T * (NP / 4); i += blockDim.x) {
+                const int t = i / (NP / 4), d = i - t * (NP / 4);
+                dst[i] = (d < n4) ? src[(size_t)t * n4 + d] : 0xffffffffu;
+            }
+        } else {
+            for (int i = threadIdx.x; i < a.T * NP; i += blockDim.x) {
+                const int t = i / NP, n = i - t * NP;
+                s_codes[i] = (n < a.N) ? a.codes[(size_t)t * a.N + n] : (uint8_t)255;
+            }
         }
-        for (int i = threadIdx.x; i < a.N * FP; i += blockDim.x) {
-            const int n = i / FP, f = i - n * FP;
-            s_w[i] = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+        if ((a.F & 3) == 0 && (a.ldw & 3) == 0 && (((uintptr_t)a.w1t) & 15) == 0) {
+            const int f4n = a.F >> 2;
+            float4 *dst = reinterpret_cast<float4 *>(s_w);
+            for (int i = threadIdx.x; i < a.N * (FP / 4); i += blockDim.x) {
+                const int n = i / (FP / 4), f4 = i - n * (FP / 4);
+                dst[i] = (f4 < f4n) ? reinterpret_cast<const float4 *>(a.w1t + (size_t)n * a.ldw)[f4]
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (int i = threadIdx.x; i < a.N * FP; i += blockDim.x) {
+                const int n = i / FP, f = i - n * FP;
+                s_w[i] = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+            }
         }
         __syncthreads();
     }

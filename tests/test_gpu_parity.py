@@ -259,3 +259,21 @@ def test_batch_chunking_is_transparent(mode, O):
     eng = _engine(w1, w2, c["roi"], c["dims"], max_batch=7)
     out = eng.forward_counts(torch.from_numpy(frames[:31]).cuda(), carry=(mode == "carry")).cpu().numpy()
     assert np.array_equal(out.astype(np.int16), G[f"out_{mode}"][:31])
+
+
+def test_output_layer_without_lds_tile(O):
+    """F = 700 (> 624): the W2^T tile does not fit in LDS at any width, weights are read through L2
+    (`k_output_counts<4, false>`); also exercises the 16-register feature variant without LDS tables."""
+    rng = np.random.default_rng(21)
+    dims, roi, T = 6, 12, 30
+    N, F, P, Q = dims * dims, 700, 333, 9
+    w1 = (rng.standard_normal((F, N)) * 0.5).astype(np.float32)
+    w2 = (rng.standard_normal((P, F)) * 0.04).astype(np.float32)
+    frames = rng.integers(0, 90, size=(Q, roi, roi)).astype(np.uint8)
+    eng = _engine(w1, w2, roi, dims, T=T)
+    assert eng.ev_scale == 1
+    U = O.rand_U(T, roi * roi)
+    for carry in (True, False):
+        eng.reset_state()
+        out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=carry).cpu().numpy()
+        assert np.array_equal(out, O.forward(frames, dims, U, w1, w2, carry=carry)) and out.sum() > 0

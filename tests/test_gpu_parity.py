@@ -277,3 +277,35 @@ def test_output_layer_without_lds_tile(O):
         eng.reset_state()
         out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=carry).cpu().numpy()
         assert np.array_equal(out, O.forward(frames, dims, U, w1, w2, carry=carry)) and out.sum() > 0
+
+
+def test_random_shape_sweep(O):
+    """A dozen random small configurations (fan-ins, feature counts on every tile width, ragged P, short and
+    long T, dense and sparse frames, both state modes): counts, sequence match and top-k all bit-exact."""
+    from lens_amd.engine import seqmatch, seqmatch_topk
+    rng = np.random.default_rng(2024)
+    shapes = [(3, 9, 40, 70, 17), (4, 8, 150, 129, 33), (5, 10, 157, 300, 16), (8, 16, 313, 64, 5), (2, 6, 1, 5, 64),
+              (7, 7, 63, 641, 31), (6, 12, 100, 257, 48), (10, 20, 200, 130, 32), (3, 3, 300, 1, 20), (4, 12, 625, 100, 9)]
+    for dims, roi, F, P, T in shapes:
+        N = dims * dims
+        Q = int(rng.integers(3, 12))
+        w1 = (rng.standard_normal((F, N)) * rng.choice([0.2, 0.8])).astype(np.float32)
+        w1[rng.random((F, N)) < 0.3] = 0
+        w2 = (rng.standard_normal((P, F)) * rng.choice([0.03, 0.3])).astype(np.float32)
+        dens = rng.choice([2, 40, 255])
+        frames = rng.integers(0, dens + 1, size=(Q, roi, roi)).astype(np.uint8)
+        frames[rng.integers(0, Q)] = 0
+        eng = _engine(w1, w2, roi, dims, T=T)
+        U = O.rand_U(T, roi * roi)
+        for carry in (False, True):
+            eng.reset_state()
+            out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=carry)
+            ref = O.forward(frames, dims, U, w1, w2, carry=carry)
+            assert np.array_equal(out.cpu().numpy(), ref), (dims, roi, F, P, T, carry)
+        for L in (1, 2):
+            if Q >= L and P >= L:
+                assert np.array_equal(seqmatch(out, L).cpu().numpy().T, O.seqmatch(ref, L))
+                K = min(25, 64)
+                gi, gv = seqmatch_topk(out, L, K)
+                oi, ov = O.topk(O.seqmatch(ref, L), K)
+                assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gv.cpu().numpy(), ov)

@@ -24,10 +24,23 @@ namespace {
 
 // Spike-stream event = two 32-bit words:
 //   word 0: f * ev_scale   (ev_scale = byte stride of one W2^T row in the output kernel's LDS tile, so the
-//           word is the LDS byte offset of feature f's weights; 1 for the non-LDS variant)
-//   word 1: float(spike count) with the sign bit set on the LAST event of a time step (counts are >= 0, the
-//           consumer uses |word 1|).  A step without spikes is one event {0, -0.0f}; {0, +0.0f} pads.
+//           word is the LDS byte offset of feature f's weights; 1 for the non-LDS variant).  Bit 31 of the
+//           FIRST event of a chunk (EV_CHUNK events) is EV_CHUNK_MIXED: some count in the chunk is not 1.
+//   word 1: float(spike count), integer valued, with
+//           sign bit (EV_LAST)            = last event of its time step
+//           mantissa LSB (EV_EMPTY_NEXT)  = (LAST events only, and only when count < 2^23, so that the bit is
+//                                           free) the step(s) that follow carry no spikes and are not written
+//   An empty step that cannot be dropped that way -- step 0, or after a count >= 2^23 -- is the explicit event
+//   {0, -0.0f}.  The tail of the last chunk is padded with {0, +1.0f}: a harmless spike after the final LAST.
+// Why empty steps can be dropped: after any step the membrane is a clip output, for which an input-free step
+// (v += 0; fire; clip) is the identity unless v == 1.0 exactly, and then it is the identity from the second
+// such step on.  v == 1.0 can only come out of the fire path, which checks EV_EMPTY_NEXT and applies that one
+// spike there.  Step 0 is kept because the incoming state (carry mode) need not be a clip output.
+// Why EV_CHUNK_MIXED: >99 % of the events are single spikes, for which fmaf(1, w, acc) is a plain add of two
+// VGPRs -- full issue rate on gfx950, while a VALU instruction with an SGPR source (the count) issues at half.
 constexpr uint32_t EV_LAST = 0x80000000u;
+constexpr uint32_t EV_EMPTY_NEXT = 1u;
+constexpr uint32_t EV_CHUNK_MIXED = 0x80000000u;
 // Events per chunk of the output kernel = events per scalar prefetch (two s_load_dwordx16).  The scalar
 // load of the next chunk is the only memory latency on the critical path (~900 cycles from L2 / Infinity
 // Cache, one prefetch in flight per wavefront because LDS and scalar memory share the LGKM counter); 16
@@ -231,6 +244,8 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
             px[i] = (selr[i] >= 0) ? (uint32_t)a.frames[(size_t)q * a.HW + selr[i]] : 0u;
         uint32_t *ev = a.events + (size_t)q * a.cap;
         uint32_t count = 0;
+        uint32_t last_word1 = 0u;   // count word of the latest LAST event (wave-uniform)
+        bool flagged = false;       // ... which carries EV_EMPTY_NEXT already
         auto load_codes = [&](int t, uint32_t (&code)[NPL]) {
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
@@ -287,11 +302,27 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                 }
             }
             uint2 *ev2 = reinterpret_cast<uint2 *>(ev);
+            // chunk of event e is mixed: set the flag on the chunk's first event (written in an earlier
+            // instruction of this wavefront, or by the caller itself when e is that first event)
+            auto mark_mixed = [&](uint32_t e) { atomicOr(&ev[2 * (e & ~(uint32_t)(EV_CHUNK - 1))], EV_CHUNK_MIXED); };
             if (total == 0) {
-                if (lane == 0) ev2[count] = make_uint2(0u, EV_LAST);
-                count += 1;
+                if (!flagged) {
+                    if (t > 0 && (last_word1 & 0x7fffffffu) < 0x4b000000u) {
+                        // first empty step of a run: flag the previous LAST event (count < 2^23: its mantissa LSB is free)
+                        if (lane == 0) ev[2 * (count - 1) + 1] = last_word1 | EV_EMPTY_NEXT;
+                        flagged = true;
+                    } else {                       // explicit empty step (see the format notes)
+                        if (lane == 0) {
+                            ev2[count] = make_uint2(0u, EV_LAST);
+                            mark_mixed(count);
+                        }
+                        count += 1;
+                        last_word1 = EV_LAST;
+                    }
+                }
             } else {
                 uint32_t base = count;
+                uint32_t spor = 0u;   // OR of the count bit patterns: above 1.0f's iff some count exceeds 1
 #pragma unroll
                 for (int j = 0; j < FPL; ++j) {
                     if (sp[j] > 0.0f) {
@@ -301,13 +332,26 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                         ev2[pos] = make_uint2((uint32_t)(j * 64 + lane) * (uint32_t)a.ev_scale, bits);
                     }
                     base += (uint32_t)__builtin_popcountll(sm[j]);
+                    spor |= __float_as_uint(sp[j]);
+                }
+                last_word1 = 0xbf800000u;               // a single spike, LAST: all but <1 % of the steps
+                if (__ballot(spor > 0x3f800000u)) {     // some count exceeds 1: after the stores above, in program order
+                    base = count;
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) {
+                        if (sp[j] > 1.0f) mark_mixed(base + lanes_below(sm[j]));
+                        base += (uint32_t)__builtin_popcountll(sm[j]);
+                        if (sm[j])
+                            last_word1 = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sp[j]), 63 - __builtin_clzll(sm[j])) | EV_LAST;
+                    }
                 }
                 count += total;
+                flagged = false;
             }
         }
-        // count is in events (2 words each); pad with null events to a whole chunk of EV_CHUNK events
+        // count is in events (2 words each); pad to a whole chunk of EV_CHUNK events with {0, +1.0f}
         const uint32_t pad = ((uint32_t)EV_CHUNK - (count & (EV_CHUNK - 1))) & (EV_CHUNK - 1);
-        if ((uint32_t)lane < pad) reinterpret_cast<uint2 *>(ev)[count + lane] = make_uint2(0u, 0u);
+        if ((uint32_t)lane < pad) reinterpret_cast<uint2 *>(ev)[count + lane] = make_uint2(0u, 0x3f800000u);
         if (lane == 0) a.nwords[q] = 2u * (count + pad);
     }
     if (a.carry) {
@@ -358,11 +402,12 @@ __device__ __forceinline__ void load_weights(const uint32_t (&e)[EV_WORDS], cons
     using vec_t = typename VecT<PPL>::type;
 #pragma unroll
     for (int i = 0; i < EV_CHUNK; ++i) {
+        const uint32_t off = i ? e[2 * i] : (e[0] & ~EV_CHUNK_MIXED);
         vec_t wv;
         if constexpr (W_LDS) {
-            wv = *reinterpret_cast<const vec_t *>(smem + (e[2 * i] + lane_off));
+            wv = *reinterpret_cast<const vec_t *>(smem + (off + lane_off));
         } else {
-            wv = *reinterpret_cast<const vec_t *>(w2t + (size_t)e[2 * i] * ldw + pl);
+            wv = *reinterpret_cast<const vec_t *>(w2t + (size_t)off * ldw + pl);
         }
         vec_unpack<PPL>(wv, w[i]);
     }
@@ -397,29 +442,40 @@ __device__ __forceinline__ uint32_t weights_token(const float (&w)[EV_CHUNK][PPL
 
 // The events of a chunk against this lane's PPL places.  All control flow is wave-uniform (the
 // event words live in SGPRs); no memory instruction in here.
-template <int PPL>
+template <int PPL, bool SINGLE>   // SINGLE: every count of the chunk is 1 (EV_CHUNK_MIXED clear)
 __device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], const float (&w)[EV_CHUNK][PPL],
                                                 float (&v)[PPL], float (&cnt)[PPL], float (&acc)[PPL])
 {
 #pragma unroll
     for (int i = 0; i < EV_CHUNK; ++i) {
-        const float sv = __builtin_fabsf(__uint_as_float(e[2 * i + 1]));
+        if constexpr (SINGLE) {
 #pragma unroll
-        for (int k = 0; k < PPL; ++k) acc[k] = __builtin_fmaf(sv, w[i][k], acc[k]);
+            for (int k = 0; k < PPL; ++k) acc[k] = acc[k] + w[i][k];   // == fmaf(1, w, acc)
+        } else {
+            const float sv = __builtin_fabsf(__uint_as_float(e[2 * i + 1] & ~EV_EMPTY_NEXT));
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) acc[k] = __builtin_fmaf(sv, w[i][k], acc[k]);
+        }
         if ((int32_t)e[2 * i + 1] < 0) {   // LAST event of the step: integrate-and-fire
             bool fire = false;
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
                 v[k] = v[k] + acc[k];
                 acc[k] = 0.0f;
-                fire |= (v[k] >= 1.0f);
+                fire |= (v[k] >= 0.99999994f);   // 1 - 2^-24 included: the clip rounds it up to exactly 1.0 (EV_EMPTY_NEXT)
             }
-            if (__builtin_amdgcn_ballot_w64(fire) != 0) {   // rare: some lane reaches threshold
+            if (__builtin_amdgcn_ballot_w64(fire) != 0) {   // some lane reaches threshold
 #pragma unroll
                 for (int k = 0; k < PPL; ++k) {
                     const float sp = __builtin_floorf(__builtin_fmaxf(v[k], 0.0f));
                     v[k] -= sp;
                     cnt[k] += sp;
+                }
+                if (e[2 * i + 1] & EV_EMPTY_NEXT) {   // dropped empty steps follow: a membrane left at exactly 1.0 fires there
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) {
+                        if (iaf_clip(v[k]) == 1.0f) { cnt[k] += 1.0f; v[k] = 0.0f; }
+                    }
                 }
             }
 #pragma unroll
@@ -485,7 +541,8 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 #pragma unroll
                 for (int i = 0; i < EV_WORDS; ++i) eb[i] = nxt[i];
             }
-            integrate_chunk<PPL>(ea, w, v, cnt, acc);
+            if (ea[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(ea, w, v, cnt, acc);
+            else integrate_chunk<PPL, true>(ea, w, v, cnt, acc);
             if (c + 1 >= nch) break;
             load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
             nxt = ev + (size_t)(c + 2) * EV_WORDS + weights_token<PPL>(w);
@@ -493,7 +550,8 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 #pragma unroll
                 for (int i = 0; i < EV_WORDS; ++i) ea[i] = nxt[i];
             }
-            integrate_chunk<PPL>(eb, w, v, cnt, acc);
+            if (eb[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(eb, w, v, cnt, acc);
+            else integrate_chunk<PPL, true>(eb, w, v, cnt, acc);
         }
         float *o = a.counts + (size_t)q * a.ldo + pl;
 #pragma unroll
@@ -1157,10 +1215,13 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     } else {
         threads = 1024;
         if (n_groups <= 0) {
-            // enough workgroups to balance 256 CUs, while every wavefront keeps >= 4 queries if it can
-            const int want = (2048 + ntiles - 1) / ntiles;
-            const int most = (Q + 63) / 64;
-            n_groups = want < most ? want : most;
+            // about 16 queries per wavefront (the 100 KB tile is staged once per workgroup), but at least one
+            // workgroup per CU; measured on Q=4096: P=1000 -> 32 groups (256 workgroups), P=100000 -> 16
+            const int fill = (256 + ntiles - 1) / ntiles;
+            const int load = (Q + 255) / 256;
+            const int most = (Q + 15) / 16;
+            n_groups = fill > load ? fill : load;
+            if (n_groups > most) n_groups = most;
             if (n_groups < 1) n_groups = 1;
         }
         if (n_groups > Q) n_groups = Q;

@@ -1,0 +1,115 @@
+// Slot-cost microbenchmark for the event loop of k_output_counts (development aid, not part of the product):
+// cycles per "event" for candidate instruction mixes at 1, 2, 4 and 8 waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <string>
+
+#define REP8(x) x x x x x x x x
+#define ITER 1000
+
+// operands: %0..%3 acc/weight-ish VGPRs (rw), %4 addr VGPR tmp (rw), %5..%6 w pair (rw 64-bit), %7 sgpr (rw)
+//           %8 lane offset VGPR, %9 counts VGPR, %10 sgpr multiplier, %11 offsets VGPR
+#define KERNEL(name, body)                                                                        \
+__global__ void __launch_bounds__(1024) name(unsigned long long *out, float seed, unsigned us) {  \
+    __shared__ float tile[8192];                                                                  \
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) tile[i] = seed + i;                      \
+    __syncthreads();                                                                              \
+    float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3;                                 \
+    unsigned addr = 0; double w = 0; unsigned s0 = us;                                            \
+    unsigned lane8 = (threadIdx.x & 63) * 8; float cntv = seed * (threadIdx.x & 15);              \
+    unsigned offs = (threadIdx.x & 15) * 512; float smul = seed;                                  \
+    typedef float v2f __attribute__((ext_vector_type(2)));                                        \
+    v2f accp = {seed, seed}, wp = {seed * 0.001f, seed * 0.002f}, half = {0.5f, 0.5f}, two = {2.0f, 2.0f}, mone = {-1.0f, -1.0f}; \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+    for (int i = 0; i < ITER; ++i) {                                                              \
+        asm volatile(body : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(addr), "+v"(w), "+s"(s0) \
+                     : "v"(lane8), "v"(cntv), "s"(smul), "v"(offs), [accp] "v"(accp), [wp] "v"(wp), [half] "v"(half), [two] "v"(two), [mone] "v"(mone) : "scc", "vcc", "s20", "s21"); \
+    }                                                                                             \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+    if (threadIdx.x % 64 == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;       \
+    if (a0 + a1 + a2 + a3 + (float)w + (float)s0 + (float)addr + accp.x + accp.y + wp.x == 12345.678f) out[0] = 0; \
+}
+
+// current kernel's event: SGPR-sourced offset and count
+#define EV_CUR "v_add_u32 %4, %6, %7\n ds_read_b64 %5, %4\n s_waitcnt lgkmcnt(3)\n v_fma_f32 %0, |%9|, %2, %0\n s_cmp_gt_i32 %6, -1\n v_fma_f32 %1, |%9|, %3, %1\n s_cbranch_scc0 1f\n 1:\n"
+KERNEL(k_cur, REP8(EV_CUR))
+// proposed: DPP row broadcast of VGPR-held offsets/counts
+#define EV_DPP "v_add_u32_dpp %4, %10, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf\n ds_read_b64 %5, %4\n s_waitcnt lgkmcnt(3)\n v_fmac_f32_dpp %0, |%8|, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_bitcmp1_b32 %6, 7\n v_fmac_f32_dpp %1, |%8|, %3 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_cbranch_scc1 1f\n 1:\n"
+KERNEL(k_dpp, REP8(EV_DPP))
+// DPP without the LDS read
+#define EV_DPPNL "v_add_u32_dpp %4, %10, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %0, |%8|, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_bitcmp1_b32 %6, 7\n v_fmac_f32_dpp %1, |%8|, %3 row_newbcast:5 row_mask:0xf bank_mask:0xf\n s_cbranch_scc1 1f\n 1:\n"
+KERNEL(k_dppnl, REP8(EV_DPPNL))
+// VALU only (3 per event)
+#define EV_V3 "v_add_u32 %4, %6, %7\n v_fma_f32 %0, |%9|, %2, %0\n v_fma_f32 %1, |%9|, %3, %1\n"
+KERNEL(k_v3, REP8(EV_V3))
+// VALU + LDS, no scalar
+#define EV_V3L "v_add_u32 %4, %6, %7\n ds_read_b64 %5, %4\n s_waitcnt lgkmcnt(3)\n v_fma_f32 %0, |%9|, %2, %0\n v_fma_f32 %1, |%9|, %3, %1\n"
+KERNEL(k_v3l, REP8(EV_V3L))
+// VALU + one scalar compare, no branch
+#define EV_V3S "v_add_u32 %4, %6, %7\n v_fma_f32 %0, |%9|, %2, %0\n s_cmp_gt_i32 %6, -1\n v_fma_f32 %1, |%9|, %3, %1\n"
+KERNEL(k_v3s, REP8(EV_V3S))
+// VALU + compare + branch (not taken)
+#define EV_V3SB "v_add_u32 %4, %6, %7\n v_fma_f32 %0, |%9|, %2, %0\n s_cmp_gt_i32 %6, -1\n v_fma_f32 %1, |%9|, %3, %1\n s_cbranch_scc0 1f\n 1:\n"
+KERNEL(k_v3sb, REP8(EV_V3SB))
+// 4 places per lane: b128 read, 4 fma
+#define EV_P4 "v_add_u32 %4, %6, %7\n ds_read_b64 %5, %4\n s_waitcnt lgkmcnt(3)\n v_fma_f32 %0, |%9|, %2, %0\n v_fma_f32 %1, |%9|, %3, %1\n s_cmp_gt_i32 %6, -1\n v_fma_f32 %2, |%9|, %0, %2\n v_fma_f32 %3, |%9|, %1, %3\n s_cbranch_scc0 1f\n 1:\n"
+KERNEL(k_p4, REP8(EV_P4))
+
+// control-flow costs on top of two VGPR adds per event
+#define EV_NT "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc0 1f\n s_nop 0\n 1:\n"
+KERNEL(k_nt, REP8(EV_NT))
+#define EV_TK "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc1 1f\n s_nop 0\n 1:\n"
+KERNEL(k_tk, REP8(EV_TK))
+#define EV_TK2 "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc1 1f\n s_nop 0\n 1:\n s_branch 2f\n s_nop 0\n 2:\n"
+KERNEL(k_tk2, REP8(EV_TK2))
+#define EV_CALL "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n s_call_b64 s[20:21], 9f\n s_branch 8f\n 9:\n s_setpc_b64 s[20:21]\n 8:\n"
+KERNEL(k_call, REP8(EV_CALL))
+#define EV_A2 "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n"
+KERNEL(k_a2, REP8(EV_A2))
+// far taken branch (out of line and back), like the LAST handler
+#define EV_FAR "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc1 7f\n 6:\n"
+KERNEL(k_far, REP8(EV_FAR) "s_branch 5f\n 7:\n s_branch 6b\n 5:\n")
+
+// single-spike event of the current kernel, with two scalar adds vs one packed add (w lands in a register pair)
+#define EV_S2 "v_add_u32 %4, %6, %7\n ds_read_b64 %5, %4\n v_add_f32 %0, %0, %2\n s_cmp_gt_i32 %6, -1\n v_add_f32 %1, %1, %3\n s_cbranch_scc0 1f\n 1:\n"
+KERNEL(k_s2, REP8(EV_S2) "s_waitcnt lgkmcnt(0)\n")
+#define EV_PK "v_add_u32 %4, %6, %7\n ds_read_b64 %5, %4\n v_pk_add_f32 %[accp], %[accp], %[wp]\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc0 1f\n 1:\n"
+KERNEL(k_pk, REP8(EV_PK) "s_waitcnt lgkmcnt(0)\n")
+// integrate-and-fire step: scalar ops vs packed ops
+#define IAF_S "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n v_max_f32 %4, %0, %1\n v_cmp_le_f32 vcc, 1.0, %4\n s_cbranch_vccz 1f\n 1:\n v_fma_f32 %0, %0, 0.5, 0.5 clamp\n v_fma_f32 %1, %1, 0.5, 0.5 clamp\n v_fma_f32 %0, %0, 2.0, -1.0\n v_fma_f32 %1, %1, 2.0, -1.0\n v_mov_b32 %2, 0\n v_mov_b32 %3, 0\n"
+KERNEL(k_iafs, REP8(IAF_S))
+#define IAF_P "v_pk_add_f32 %[accp], %[accp], %[wp]\n v_max_f32 %4, %0, %1\n v_cmp_le_f32 vcc, 1.0, %4\n s_cbranch_vccz 1f\n 1:\n v_pk_fma_f32 %[accp], %[accp], %[half], %[half] clamp\n v_pk_fma_f32 %[accp], %[accp], %[two], %[mone]\n v_mov_b64 %[wp], 0\n"
+KERNEL(k_iafp, REP8(IAF_P))
+
+template <typename K>
+void run(const char *name, K kern) {
+    unsigned long long *d; hipMalloc(&d, 512 * 16 * 8);
+    struct Cfg { int blocks, threads; };
+    for (Cfg c : {Cfg{256, 256}, Cfg{256, 512}, Cfg{256, 1024}, Cfg{512, 1024}}) {
+        hipLaunchKernelGGL(kern, dim3(c.blocks), dim3(c.threads), 0, 0, d, 1.0f, 1u);
+        { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { printf("%s: %s\n", name, hipGetErrorString(e)); return; } }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(c.blocks), dim3(c.threads), 0, 0, d, 1.0f, 1u);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double events = (double)ITER * 8;                     // per wave
+        const double waves_per_simd = (double)c.blocks * c.threads / 64 / 1024;
+        // wall time per event per SIMD, in ns (all SIMDs busy): ms*1e6 / (events * waves_per_simd)
+        printf("%-8s waves/SIMD %.0f  wall ns/event/wave %.3f   ns/event/SIMD %.3f\n",
+               name, waves_per_simd, ms * 1e6 / events, ms * 1e6 / (events * waves_per_simd));
+    }
+    hipFree(d);
+}
+
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    std::string w = argc > 1 ? argv[1] : "all";
+#define RUN(n, k) if (w == "all" || w == n) run(n, k);
+    RUN("cur", k_cur) RUN("dpp", k_dpp) RUN("dpp_nolds", k_dppnl) RUN("valu3", k_v3) RUN("valu3+lds", k_v3l)
+    RUN("valu3+s", k_v3s) RUN("valu3+sb", k_v3sb) RUN("ppl4", k_p4)
+    RUN("ev_s2", k_s2) RUN("ev_pk", k_pk) RUN("iaf_s", k_iafs) RUN("iaf_p", k_iafp)
+    RUN("add2", k_a2) RUN("add2+nt", k_nt) RUN("add2+tk", k_tk) RUN("add2+tk2", k_tk2) RUN("add2+call", k_call)
+    return 0;
+}

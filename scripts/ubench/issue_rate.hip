@@ -50,6 +50,20 @@ KERNEL(k_cmp,   REP16("v_cmp_gt_f32 vcc, %0, %12\n v_cmp_gt_f32 vcc, %1, %12\n v
 KERNEL(k_cnd,   REP16("v_cndmask_b32 %0, %0, %12, vcc\n v_cndmask_b32 %1, %1, %12, vcc\n v_cndmask_b32 %2, %2, %12, vcc\n v_cndmask_b32 %3, %3, %12, vcc\n v_cndmask_b32 %4, %4, %12, vcc\n v_cndmask_b32 %5, %5, %12, vcc\n v_cndmask_b32 %6, %6, %12, vcc\n v_cndmask_b32 %7, %7, %12, vcc\n"))
 KERNEL(k_and,   V8("v_and_b32", ", %12"))
 KERNEL(k_maxi,  V8("v_max_i32", ", %12"))
+KERNEL(k_or,    V8("v_or_b32", ", %12"))
+KERNEL(k_or3,   V8("v_or3_b32", ", %12, %13"))
+KERNEL(k_bfi,   V8("v_bfi_b32", ", %12, %13"))
+KERNEL(k_andor, V8("v_and_or_b32", ", %12, %13"))
+KERNEL(k_lshladd, V8("v_lshl_add_u32", ", 3, %13"))
+KERNEL(k_addco, REP16("v_add_co_u32 %0, vcc, %0, %12\n v_add_co_u32 %1, vcc, %1, %12\n v_add_co_u32 %2, vcc, %2, %12\n v_add_co_u32 %3, vcc, %3, %12\n v_add_co_u32 %4, vcc, %4, %12\n v_add_co_u32 %5, vcc, %5, %12\n v_add_co_u32 %6, vcc, %6, %12\n v_add_co_u32 %7, vcc, %7, %12\n"))
+KERNEL(k_fmac,  V8("v_fmac_f32", ", %12"))
+KERNEL(k_cmpu,  REP16("v_cmp_le_u32 vcc, %12, %0\n v_cmp_le_u32 vcc, %12, %1\n v_cmp_le_u32 vcc, %12, %2\n v_cmp_le_u32 vcc, %12, %3\n v_cmp_le_u32 vcc, %12, %4\n v_cmp_le_u32 vcc, %12, %5\n v_cmp_le_u32 vcc, %12, %6\n v_cmp_le_u32 vcc, %12, %7\n"))
+KERNEL(k_fmadpp, V8("v_fmac_f32_dpp", ", %12 row_newbcast:3 row_mask:0xf bank_mask:0xf"))
+KERNEL(k_fmas,  V8("v_fma_f32", ", s9, %13"))
+KERNEL(k_fmasabs, REP16("v_fma_f32 %0, |s9|, %12, %0\n v_fma_f32 %1, |s9|, %12, %1\n v_fma_f32 %2, |s9|, %12, %2\n v_fma_f32 %3, |s9|, %12, %3\n v_fma_f32 %4, |s9|, %12, %4\n v_fma_f32 %5, |s9|, %12, %5\n v_fma_f32 %6, |s9|, %12, %6\n v_fma_f32 %7, |s9|, %12, %7\n"))
+KERNEL(k_fmaacc, REP16("v_fma_f32 %0, %13, %12, %0\n v_fma_f32 %1, %13, %12, %1\n v_fma_f32 %2, %13, %12, %2\n v_fma_f32 %3, %13, %12, %3\n v_fma_f32 %4, %13, %12, %4\n v_fma_f32 %5, %13, %12, %5\n v_fma_f32 %6, %13, %12, %6\n v_fma_f32 %7, %13, %12, %7\n"))
+KERNEL(k_fmaacc2, REP16("v_fma_f32 %0, %13, %12, %0\n v_fma_f32 %1, %13, %12, %1\n v_fma_f32 %0, %13, %12, %0\n v_fma_f32 %1, %13, %12, %1\n v_fma_f32 %0, %13, %12, %0\n v_fma_f32 %1, %13, %12, %1\n v_fma_f32 %0, %13, %12, %0\n v_fma_f32 %1, %13, %12, %1\n"))
+KERNEL(k_addus, V8("v_add_u32", ", s9"))
 
 
 KERNEL(k_salu2, REP16("s_and_b32 %8, %8, %9\n s_and_b32 %9, %9, %10\n s_and_b32 %10, %10, %11\n s_and_b32 %11, %11, %8\n s_and_b32 %8, %8, %9\n s_and_b32 %9, %9, %10\n s_and_b32 %10, %10, %11\n s_and_b32 %11, %11, %8\n"))
@@ -109,5 +123,8 @@ int main(int argc, char **argv) {
     RUN("rndne", k_rndne, 8) RUN("cvt_u32_f32", k_cvtu, 8) RUN("cvt_f32_u32", k_cvtf, 8) RUN("med3", k_med3, 8)
     RUN("max3", k_max3, 8) RUN("add_clamp", k_addcl, 8) RUN("cmp", k_cmp, 8) RUN("cndmask", k_cnd, 8)
     RUN("and", k_and, 8) RUN("max_i32", k_maxi, 8)
+    RUN("or", k_or, 8) RUN("or3", k_or3, 8) RUN("bfi", k_bfi, 8) RUN("and_or", k_andor, 8) RUN("lshl_add", k_lshladd, 8)
+    RUN("add_co", k_addco, 8) RUN("fmac", k_fmac, 8) RUN("cmp_u32", k_cmpu, 8) RUN("fmac_dpp", k_fmadpp, 8)
+    RUN("fma_s", k_fmas, 8) RUN("fma_sabs", k_fmasabs, 8) RUN("fma_acc", k_fmaacc, 8) RUN("fma_acc2", k_fmaacc2, 8) RUN("addu_s", k_addus, 8)
     return 0;
 }

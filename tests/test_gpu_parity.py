@@ -309,3 +309,95 @@ def test_random_shape_sweep(O):
                 gi, gv = seqmatch_topk(out, L, K)
                 oi, ov = O.topk(O.seqmatch(ref, L), K)
                 assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gv.cpu().numpy(), ov)
+
+
+def _encode_stream(steps, ev_scale, chunk=16):
+    """Spike stream of one query in the layout documented at the top of lens_kernels.hip (white-box helper):
+    steps = per time step a list of (feature, count) in ascending feature order."""
+    ev = []                                   # [offset word, count word]
+    flagged = False
+    for t, st in enumerate(steps):
+        if not st:
+            if flagged:
+                continue
+            last_mag = (ev[-1][1] & 0x7fffffff) if ev else 0
+            if t > 0 and last_mag < 0x4b000000:
+                ev[-1][1] |= 1                # EV_EMPTY_NEXT on the previous LAST event
+                flagged = True
+            else:
+                ev.append([0, 0x80000000])    # explicit empty step
+            continue
+        for k, (f, c) in enumerate(st):
+            bits = int(np.float32(c).view(np.uint32))
+            if k == len(st) - 1:
+                bits |= 0x80000000
+            ev.append([f * ev_scale, bits])
+        flagged = False
+    while len(ev) % chunk:
+        ev.append([0, 0x3f800000])
+    for c0 in range(0, len(ev), chunk):
+        if any(((w1 & 0x7ffffffe) != 0x3f800000) for _, w1 in ev[c0:c0 + chunk]):
+            ev[c0][0] |= 0x80000000           # EV_CHUNK_MIXED
+    return np.array(ev, dtype=np.uint32).reshape(-1)
+
+
+@pytest.mark.parametrize("F", [2, 200, 400, 700])    # 4, 2, 1 places per lane, and the tile read through L2
+def test_stream_consumer_dropped_steps(O, F):
+    """lens_output_counts on hand-built streams against the oracle's dense Linear + IAF, step by step.  The
+    streams leave out the steps without spikes; the cases where such a step is not a no-op are all here:
+    a membrane that the clip leaves at exactly 1.0 (weight 1 - 2^-24) fires in the first dropped step, an
+    empty step 0 on carried state, counts > 1 (mixed chunks) and >= 2^23 (no room for the flag bit)."""
+    import ctypes
+    pred1 = float(np.nextafter(np.float32(1.0), np.float32(0.0)))
+    P = 5
+    w2 = np.zeros((P, F), dtype=np.float32)
+    w2[:, 0] = [pred1, 0.3, pred1, 0.45, 1e-7]    # a lone spike of feature 0 on rested membranes: nobody reaches 1.0,
+    w2[:, 1] = [-1.0, 0.2, pred1, 1.5, 1e-7]      # places 0 and 2 land on 1 - 2^-24, which the clip rounds up to 1.0
+    big = float(2 ** 23)
+    queries = [
+        [[], [(0, 1)], [], [(1, 1)], [], [], [(0, 1), (1, 2)], [], [(0, 1)], [], [(0, 3)], [(0, 1)], [(1, 1)], []],
+        [[(0, 1)], [], [], [(0, 1)], [(1, big)], [], [(1, 1)], [(0, 1), (1, 1)], [], [(0, 1)], [], [], [], [(0, 1)]],
+        [[], [], [], [(1, 1)], [(0, 1)], [], [(0, 1)], [], [(0, 1)], [], [(0, 1)], [], [(0, 2), (1, 5)], []],
+        [[(0, 1)]] * 3 + [[]] * 30 + [[(0, 1), (1, 1)]] * 17 + [[]],
+    ]
+    T = max(len(q) for q in queries)
+    queries = [q + [[]] * (T - len(q)) for q in queries]
+    w1 = np.zeros((F, 1), dtype=np.float32)
+    eng = _engine(w1, w2, 1, 1, T=max(T, 4))
+    Q = len(queries)
+    eng._workspace(Q)
+    words = np.zeros((Q, eng.cap), dtype=np.uint32)
+    nw = np.zeros(Q, dtype=np.int32)
+    for q, steps in enumerate(queries):
+        enc = _encode_stream(steps, eng.ev_scale)
+        words[q, :enc.size] = enc
+        nw[q] = enc.size
+    eng.events[:Q].copy_(torch.from_numpy(words.view(np.int32)))
+    eng.nwords[:Q].copy_(torch.from_numpy(nw))
+    L = O.lib()
+    fp = ctypes.POINTER(ctypes.c_float)
+    ptr = lambda a: a.ctypes.data_as(fp)
+    for carry in (False, True):
+        eng.reset_state()
+        if carry:   # a carried state that is not a clip output: step 0 may not be dropped
+            v0 = np.array([1.0, 2.5, -3.0, 0.99999994, 1e-30], dtype=np.float32)
+            eng.v_out.copy_(torch.from_numpy(v0).cuda()[None, :])
+        got = eng.output_counts(Q, carry=carry).cpu().numpy()
+        v = v0.copy() if carry else None
+        ref = np.zeros((Q, P), dtype=np.float32)
+        for q, steps in enumerate(queries):
+            if not carry:
+                v = np.zeros(P, dtype=np.float32)
+            for st in steps:
+                x = np.zeros(F, dtype=np.float32)
+                for f, c in st:
+                    x[f] = c
+                cur = np.zeros(P, dtype=np.float32)
+                spk = np.zeros(P, dtype=np.float32)
+                L.lens_oracle_linear(ptr(x), ptr(w2), ptr(cur), F, P)
+                L.lens_oracle_iaf_step(ptr(v), ptr(cur), ptr(spk), P)
+                ref[q] += spk
+        assert np.array_equal(got, ref), (F, carry, got, ref)
+        if carry:
+            assert np.array_equal(eng.v_out.cpu().numpy()[0], v)
+    assert ref[0, 0] != 0 or ref[3, 2] != 0

@@ -420,23 +420,12 @@ __device__ __forceinline__ void load_weights(const uint32_t (&e)[EV_WORDS], cons
 template <int PPL>
 __device__ __forceinline__ uint32_t weights_token(const float (&w)[EV_CHUNK][PPL])
 {
-    uint32_t tok = 0;
-#pragma unroll
-    for (int i = 0; i < EV_CHUNK; i += 4) {       // 4 events per asm statement (<= 16 inputs, limit is 30)
-        uint32_t t;
-        if constexpr (PPL == 1) {
-            asm("s_mov_b32 %0, 0" : "=s"(t) : "v"(w[i][0]), "v"(w[i + 1][0]), "v"(w[i + 2][0]), "v"(w[i + 3][0]));
-        } else if constexpr (PPL == 2) {
-            asm("s_mov_b32 %0, 0" : "=s"(t) : "v"(w[i][0]), "v"(w[i][1]), "v"(w[i + 1][0]), "v"(w[i + 1][1]),
-                                              "v"(w[i + 2][0]), "v"(w[i + 2][1]), "v"(w[i + 3][0]), "v"(w[i + 3][1]));
-        } else {
-            asm("s_mov_b32 %0, 0" : "=s"(t) : "v"(w[i][0]), "v"(w[i][1]), "v"(w[i][2]), "v"(w[i][3]),
-                                              "v"(w[i + 1][0]), "v"(w[i + 1][1]), "v"(w[i + 1][2]), "v"(w[i + 1][3]),
-                                              "v"(w[i + 2][0]), "v"(w[i + 2][1]), "v"(w[i + 2][2]), "v"(w[i + 2][3]),
-                                              "v"(w[i + 3][0]), "v"(w[i + 3][1]), "v"(w[i + 3][2]), "v"(w[i + 3][3]));
-        }
-        tok |= t;
-    }
+    // one read instruction per event returns all PPL components, so the first component of every event covers them all
+    uint32_t tok;
+    static_assert(EV_CHUNK == 16, "operand list below");
+    asm("s_mov_b32 %0, 0" : "=s"(tok)
+        : "v"(w[0][0]), "v"(w[1][0]), "v"(w[2][0]), "v"(w[3][0]), "v"(w[4][0]), "v"(w[5][0]), "v"(w[6][0]), "v"(w[7][0]),
+          "v"(w[8][0]), "v"(w[9][0]), "v"(w[10][0]), "v"(w[11][0]), "v"(w[12][0]), "v"(w[13][0]), "v"(w[14][0]), "v"(w[15][0]));
     return tok;
 }
 
@@ -534,9 +523,11 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         float w[EV_CHUNK][PPL];
 #pragma unroll
         for (int i = 0; i < EV_WORDS; ++i) ea[i] = ev[i];
+        const char *p = reinterpret_cast<const char *>(ev);   // chunk being integrated (byte pointer: the token adds unshifted)
         for (int c = 0; c < nch; c += 2) {
             load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, w);
-            const uint32_t *nxt = ev + (size_t)(c + 1) * EV_WORDS + weights_token<PPL>(w);
+            p += EV_WORDS * 4;
+            const uint32_t *nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
             if (c + 1 < nch) {
 #pragma unroll
                 for (int i = 0; i < EV_WORDS; ++i) eb[i] = nxt[i];
@@ -545,7 +536,8 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
             else integrate_chunk<PPL, true>(ea, w, v, cnt, acc);
             if (c + 1 >= nch) break;
             load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
-            nxt = ev + (size_t)(c + 2) * EV_WORDS + weights_token<PPL>(w);
+            p += EV_WORDS * 4;
+            nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
             if (c + 2 < nch) {
 #pragma unroll
                 for (int i = 0; i < EV_WORDS; ++i) ea[i] = nxt[i];

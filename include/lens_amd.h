@@ -98,10 +98,14 @@ int lens_event_scale(int F);
  * at the end.  carry == 0: state is zeroed before every query, d_vfeat is not touched (may be
  * NULL), n_streams only sets the parallelism (<= 0: one stream per query).
  *
- * Output stream of query q, d_events + q*cap_words, d_nwords[q] words (a multiple of 32):
- *   per time step, the spiking features in ascending f as two-word events
- *       word 0 = f * ev_scale,  word 1 = float(spike count), sign bit set on the LAST event of the step
- *   (a step without spikes is one event {0, -0.0f}); null events {0, +0.0f} pad to a multiple of 32 words.
+ * Output stream of query q, d_events + q*cap_words, d_nwords[q] words (a multiple of 32).  The layout is
+ * private to this library (lens_output_counts is its only consumer) and may change with the ABI version:
+ *   per time step that has spikes, the spiking features in ascending f as two-word events
+ *       word 0 = f * ev_scale (bit 31 of the first event of each 16-event chunk: some count in the chunk is not 1)
+ *       word 1 = float(spike count); sign bit = LAST event of the step; mantissa LSB (LAST events with a
+ *                count < 2^23 only) = the following step(s) have no spikes and are not written at all
+ *   a step without spikes that cannot be dropped that way (step 0, or after a count >= 2^23) is the event
+ *   {0, -0.0f}; {0, +1.0f} pads to a multiple of 32 words.  Dropping is exact: see lens_kernels.hip.
  * d_featspk (optional, NULL to skip): float [Q][T][F] dense spike counts.
  * Limits: N <= 1024, F <= 2048, cap_words >= lens_event_capacity_words(T, F), ev_scale * F < 2^31.
  */

@@ -246,3 +246,24 @@ def test_createPR_matches_the_reference():
     assert np.array_equal(np.array(P, np.float64), PR["lens_P"]) and np.array_equal(np.array(R, np.float64), PR["lens_R"])
     P2, R2 = createPR(G["S_carry"], G["GTtol"].astype(int), None, matching="multi", n_thresh=7)
     assert len(P2) == 8 and P2[0] == 1 and R2[0] == 0 and R2[-1] == 1.0
+
+
+def test_event_windows_skip_empty_windows(tmp_path):
+    """Host side of the event-list ingest: windows of `timebin` ms, windows without events give no frame
+    (lens/collect_data.py:193-204), timestamps must be ordered."""
+    from lens_amd.events import window_events, load_event_text
+    t = np.array([10, 11, 999, 1000, 1000, 2999, 7000, 7001], dtype=np.float64)          # microseconds
+    off, win = window_events(t, timebin_ms=1.0)                                            # 1 ms = 1000 ticks
+    assert off.tolist() == [0, 5, 6, 8] and win.tolist() == [0, 2, 6]                     # t0 = first event (t = 10)
+    off, win = window_events(t, timebin_ms=1.0, t0=0.0)
+    assert off.tolist() == [0, 3, 5, 6, 8] and win.tolist() == [0, 1, 2, 7]
+    off, win = window_events(np.zeros(0), 1.0)
+    assert off.tolist() == [0] and win.size == 0
+    with pytest.raises(ValueError):
+        window_events(np.array([5.0, 4.0]), 1.0)
+    with pytest.raises(ValueError):
+        window_events(t, 1.0, t0=50.0)
+    p = tmp_path / "ev.txt"
+    p.write_text("128 128\n100 3 4 1\n250.5 7 8 0\n")
+    tt, x, y, pol = load_event_text(str(p))
+    assert tt.tolist() == [100.0, 250.5] and x.tolist() == [3, 7] and y.tolist() == [4, 8] and pol.tolist() == [1, 0]

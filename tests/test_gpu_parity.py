@@ -401,3 +401,23 @@ def test_stream_consumer_dropped_steps(O, F):
         if carry:
             assert np.array_equal(eng.v_out.cpu().numpy()[0], v)
     assert ref[0, 0] != 0 or ref[3, 2] != 0
+
+
+def test_event_list_ingest_matches_oracle(O):
+    """Timestamped events -> time windows -> count frames in one launch; checked against the oracle's
+    restatement of create_images (lens/collect_data.py:193-199) window by window."""
+    from lens_amd.events import frames_from_events, window_events
+    rng = np.random.default_rng(5)
+    n, roi = 200_000, 64
+    t = np.sort(rng.integers(0, 40_000_000, size=n)).astype(np.float64)        # 40 s of microsecond stamps
+    t[(t > 7e6) & (t < 12.5e6)] = 7e6                                          # a silent stretch: windows without events
+    x = rng.integers(1, roi + 1, size=n)
+    y = rng.integers(1, roi + 1, size=n)
+    x[:3000] = 5; y[:3000] = 9                                                 # > 255 hits on one pixel: uint8 wrap
+    frames, win = frames_from_events(t, x, y, timebin_ms=1000.0, roi_dim=roi)
+    off, win2 = window_events(t, 1000.0)
+    assert np.array_equal(win, win2) and len(win) < 40 and win[-1] == 39
+    ref = O.accumulate_events(x, y, off, roi)
+    assert np.array_equal(frames.cpu().numpy(), ref)
+    with pytest.raises(IndexError):
+        frames_from_events(t[:10], np.full(10, roi + 70), y[:10], 1000.0, roi)

@@ -43,6 +43,8 @@ def window_events(t, timebin_ms, t_unit_s=1e-6, t0=None):
     dt = float(timebin_ms) * 1e-3 / float(t_unit_s)
     if not dt > 0:
         raise ValueError("timebin must be positive")
+    if abs(dt - round(dt)) <= 1e-9 * dt:      # 1e-3 / 1e-6 is not exactly 1000 in binary floating point
+        dt = float(round(dt))
     start = t[0] if t0 is None else float(t0)
     if t[0] < start:
         raise ValueError("t0 lies after the first event")

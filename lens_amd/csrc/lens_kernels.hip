@@ -47,6 +47,7 @@ constexpr uint32_t EV_CHUNK_MIXED = 0x80000000u;
 // events of compute per exposure keep four wavefronts per SIMD busy (8 events did not: DESIGN.md section 5).
 constexpr int EV_CHUNK = 16;
 constexpr int EV_WORDS = 2 * EV_CHUNK;
+constexpr int OUT_ORDER_MAX = 512;    // largest query group the output kernel sorts by stream length
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 {
@@ -480,11 +481,17 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
     constexpr int PT = 64 * PPL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nw = blockDim.x >> 6;
     const int tile = blockIdx.x % a.ntiles;
     const int grp = blockIdx.x / a.ntiles;
     const int p0 = tile * PT;
 
+    // Queries of the group are handed to the wavefronts first come, first served: stream lengths vary by +-20 %
+    // (std) between queries, and with a fixed assignment the slowest of the 16 wavefronts sets the pace (+14 %
+    // on average, +26 % for the slowest workgroup at P=1000).
+    __shared__ int s_next;
+    __shared__ uint16_t s_order[OUT_ORDER_MAX];   // longest stream first (when the group is small enough to rank)
+    __shared__ uint32_t s_len[OUT_ORDER_MAX];
+    if (threadIdx.x == 0) s_next = 0;
     if constexpr (W_LDS) {
         float4 *dst = reinterpret_cast<float4 *>(smem);
         const int n4 = a.F * (PT / 4);
@@ -492,10 +499,29 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
             const int f = i / (PT / 4), c = i - f * (PT / 4);
             dst[i] = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
         }
-        __syncthreads();
     }
     const int qs = (int)(((long long)grp * a.Q) / a.n_groups);
     const int qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
+    const int nq = qe - qs;
+    // Longest first pays when the whole grid is one or two rounds of workgroups (the tail of the slowest one is the
+    // kernel's tail); with many rounds the dispatcher evens things out and the O(nq^2) ranking is a net loss.
+    const bool ranked = !a.carry && nq <= OUT_ORDER_MAX && gridDim.x <= 512;
+    if (ranked) {
+        for (int t = threadIdx.x; t < nq; t += blockDim.x) s_len[t] = a.nwords[qs + t];
+    }
+    __syncthreads();
+    if (ranked) {   // rank by counting: position of query t = number of queries that come before it
+        for (int t = threadIdx.x; t < nq; t += blockDim.x) {
+            const uint32_t mine = s_len[t];
+            int r = 0;
+            for (int j = 0; j < nq; ++j) {
+                const uint32_t other = s_len[j];
+                r += (other > mine || (other == mine && j < t)) ? 1 : 0;
+            }
+            s_order[r] = (uint16_t)t;
+        }
+        __syncthreads();
+    }
     const int pl = p0 + lane * PPL;   // first place of this lane
 
     float v[PPL], cnt[PPL], acc[PPL];
@@ -506,9 +532,17 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 #pragma unroll
         for (int k = 0; k < PPL; ++k) v[k] = (pl + k < a.P) ? a.vout[(size_t)grp * a.ldv + pl + k] : 0.0f;
     }
-    const int qstep = a.carry ? 1 : nw;
     const uint32_t lane_off = (uint32_t)lane * (PPL * 4);
-    for (int q = qs + (a.carry ? 0 : wave); q < qe; q += qstep) {
+    for (int it = 0;; ++it) {
+        int q = qs + it;                       // carry: the one wavefront walks the group in order
+        if (!a.carry) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&s_next, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= nq) break;
+            q = qs + (ranked ? (int)s_order[t] : t);
+        }
+        if (q >= qe) break;
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
             if (!a.carry) v[k] = 0.0f;
@@ -1146,7 +1180,7 @@ size_t lens_event_capacity_words(int T, int F)
 static int output_ppl(int F)
 {
     for (int c : {4, 2, 1})
-        if ((size_t)F * 64 * c * 4 <= (size_t)LDS_BUDGET - 1024) return c;
+        if ((size_t)F * 64 * c * 4 <= (size_t)LDS_BUDGET - 4096) return c;
     return 0;
 }
 

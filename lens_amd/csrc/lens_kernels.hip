@@ -741,6 +741,23 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (u == 0 && c0 == 0) {
+                // The list is empty: instead of 64 serial insertions, rank the first chunk by counting (position =
+                // number of candidates that beat this one) and scatter it into place.  Lanes without a candidate
+                // (n_places < 64) carry (-1, -1), lose to every real one and keep their lane order among themselves.
+                const float n0 = (j[0] >= 0) ? n[0] : -1.0f;
+                int rank = 0;
+                for (int l = 0; l < 64; ++l) {
+                    const float cn = bcast(n0, l);
+                    const int cj = bcast(j[0], l);
+                    rank += (beats(cn, cj, n0, j[0]) || (cj < 0 && j[0] < 0 && l < lane)) ? 1 : 0;
+                }
+                ln = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(n0)));
+                lj = __builtin_amdgcn_ds_permute(rank << 2, j[0]);
+                tn = bcast(ln, K - 1);
+                tj = bcast(lj, K - 1);
+                continue;
+            }
             uint64_t m = __ballot(j[u] >= 0 && beats(n[u], j[u], tn, tj));
             while (m) {
                 const int b = __builtin_ctzll(m);

@@ -1,0 +1,102 @@
+"""Full BASELINE sizes (config 3: 100 000 places, 4096 queries of 128x128 synthetic frames, T=250, L=2,
+top-25) through the C ABI.  The oracle cannot run this size, so the checks are the size-independent
+properties of the path, plus exact oracle parity on a scattered sample:
+
+  * output neurons are independent given the spike streams  -> the counts of sampled places for sampled
+    queries equal the oracle run on exactly those database rows (bit-exact);
+  * duplicated database rows planted in far-apart tiles / query groups give identical columns;
+  * the run is deterministic (two passes are identical);
+  * top-k: values sorted, indices distinct, equal to a stable argsort of the similarity column rebuilt from
+    the GPU counts for sampled queries, and shard + halo + merge == unsharded at full size.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import pretrained_example
+
+pytestmark = pytest.mark.gpu
+
+P, Q, T, L, K = 100_000, 4096, 250, 2, 25
+
+
+@pytest.fixture(scope="module")
+def run():
+    from lens_amd.engine import LensEngine
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    w2 = synthetic_database(w2p, P).numpy()
+    dup = [(5, 99_990), (127, 128), (64_000, 12_345), (70_001, 3)]          # (source, copy) rows
+    for s, d in dup:
+        w2[d] = w2[s]
+    frames = synthetic_frames(Q, 128)
+    eng = LensEngine(w1, w2, 128, 10, T, device="cuda", max_batch=Q)
+    fr = frames.cuda()
+    out = eng.forward_counts(fr, carry=False)
+    return dict(eng=eng, w1=np.asarray(w1, np.float32), w2=w2, frames=frames.numpy(), fr=fr, out=out, dup=dup)
+
+
+def test_sampled_places_and_queries_match_the_oracle(run):
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    places = np.unique(np.concatenate([[0, 1, 127, 128, 129, P - 129, P - 128, P - 1], rng.integers(0, P, 120)]))
+    queries = np.unique(np.concatenate([[0, 1, 15, 16, 255, 256, Q - 1], rng.integers(0, Q, 57)]))
+    U = O.rand_U(T, 128 * 128)
+    ref = O.forward(run["frames"][queries], 10, U, run["w1"], np.ascontiguousarray(run["w2"][places]), carry=False,
+                    skip_zero=True)
+    got = run["out"][torch.from_numpy(queries).cuda()][:, torch.from_numpy(places).cuda()].cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert ref.sum() > 0
+
+
+def test_duplicate_rows_and_determinism(run):
+    out = run["out"]
+    for s, d in run["dup"]:
+        assert torch.equal(out[:, s], out[:, d]), (s, d)
+    again = run["eng"].forward_counts(run["fr"], carry=False)
+    assert torch.equal(again, out)
+    assert float(out.min()) >= 0 and torch.equal(out, out.round())          # spike counts
+
+
+def test_topk_properties_and_sharding_at_full_size(run):
+    from lens_amd.engine import seqmatch_topk, topk_merge
+    out = run["out"]
+    idx, val = seqmatch_topk(out, L, K)
+    assert idx.shape == (Q - L + 1, K)
+    v = val.cpu().numpy()
+    i = idx.cpu().numpy()
+    assert np.all(v[:, :-1] >= v[:, 1:])
+    assert np.all((i >= 0) & (i < P - L + 1))
+    assert all(len(set(r)) == K for r in i[::97])
+    # policy: score descending, then place index descending == the tail of a stable ascending argsort
+    for q in (0, 1, 777, 2048, Q - L):
+        s = (out[q, :P - L + 1] + out[q + 1, 1:P - L + 2]).cpu().numpy() / np.float32(L)
+        order = np.argsort(s, kind="stable")[-K:][::-1]
+        assert np.array_equal(i[q], order) and np.array_equal(v[q], s[order])
+    # 8 shards with an (L-1)-column halo, global indices, one merge
+    Ps, R = P - L + 1, 8
+    bounds = [r * Ps // R for r in range(R + 1)]
+    pi, pv = [], []
+    for r in range(R):
+        p0, p1 = bounds[r], bounds[r + 1]
+        shard = out[:, p0:p1 + L - 1].contiguous()
+        a, b = seqmatch_topk(shard, L, K, n_places=p1 - p0, place_offset=p0)
+        pi.append(a); pv.append(b)
+    mi, mv = topk_merge(torch.stack(pi), torch.stack(pv))
+    assert torch.equal(mi, idx) and torch.equal(mv, val)
+
+
+def test_config2_full_batch_sampled_queries_match_the_oracle():
+    """Config 2 (1000 places, 4096 queries): every place, 200 scattered queries, against the oracle."""
+    from oracle import oracle as O
+    from lens_amd.engine import LensEngine
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    w2 = synthetic_database(w2p, 1000).numpy()
+    frames = synthetic_frames(Q, 128)
+    eng = LensEngine(w1, w2, 128, 10, T, device="cuda", max_batch=Q)
+    out = eng.forward_counts(frames.cuda(), carry=False)
+    queries = np.unique(np.concatenate([[0, 15, 16, 127, 128, Q - 1], np.random.default_rng(3).integers(0, Q, 194)]))
+    ref = O.forward(frames.numpy()[queries], 10, O.rand_U(T, 128 * 128), np.asarray(w1, np.float32), w2, carry=False,
+                    skip_zero=True)
+    assert np.array_equal(out[torch.from_numpy(queries).cuda()].cpu().numpy(), ref)

@@ -1,0 +1,52 @@
+"""Randomised parity fuzz (development aid): random layer shapes, weight scales, frame densities and state modes,
+GPU path vs the CPU oracle, bit-exact.  Usage: fuzz_parity.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lens_amd.engine import LensEngine, seqmatch, seqmatch_topk
+from oracle import oracle as O
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0 = time.time()
+for case in range(n_cases):
+    dims = int(rng.integers(1, 12))
+    k = int(rng.integers(1, 4))
+    roi = dims * k
+    N = dims * dims
+    F = int(rng.choice([1, 3, 17, 64, 65, 130, 156, 157, 200, 256, 312, 313, 400, 624, 640, 900]))
+    P = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 500, 1000, 1300]))
+    T = int(rng.choice([1, 2, 7, 16, 33, 100, 250]))
+    Q = int(rng.integers(1, 20))
+    w1s, w2s = rng.choice([0.05, 0.3, 1.0, 4.0]), rng.choice([0.01, 0.1, 0.5, 2.0])
+    w1 = (rng.standard_normal((F, N)) * w1s).astype(np.float32)
+    w1[rng.random((F, N)) < rng.choice([0.0, 0.5, 0.9])] = 0
+    w2 = (rng.standard_normal((P, F)) * w2s).astype(np.float32)
+    if rng.random() < 0.3:
+        w2[rng.integers(0, P)] = np.float32(np.nextafter(np.float32(1), np.float32(0)))   # rows that land on 1 - 2^-24
+    if rng.random() < 0.2:
+        w1[rng.integers(0, F)] = 1.0e7                                                    # spike counts >= 2^23
+    dens = rng.choice([1, 3, 30, 255])
+    frames = rng.integers(0, dens + 1, size=(Q, roi, roi)).astype(np.uint8)
+    frames[rng.random((Q, roi, roi)) < rng.choice([0.0, 0.7, 0.97])] = 0
+    if rng.random() < 0.3:
+        frames[rng.integers(0, Q)] = 0
+    eng = LensEngine(w1, w2, roi, dims, T, device="cuda")
+    U = O.rand_U(T, roi * roi)
+    for carry in (False, True):
+        eng.reset_state()
+        out = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=carry)
+        ref = O.forward(frames, dims, U, w1, w2, carry=carry)
+        if not np.array_equal(out.cpu().numpy(), ref, equal_nan=True):
+            print("MISMATCH", dict(case=case, dims=dims, k=k, F=F, P=P, T=T, Q=Q, w1s=w1s, w2s=w2s, dens=dens, carry=carry))
+            sys.exit(1)
+    L = int(rng.choice([1, 2, 3]))
+    if Q >= L and P >= L and np.isfinite(ref).all():
+        S = O.seqmatch(ref, L)
+        assert np.array_equal(seqmatch(out, L).cpu().numpy().T, S), ("seqmatch", case)
+        K = int(min(25, 64))
+        gi, gv = seqmatch_topk(out, L, K)
+        oi, ov = O.topk(S, K)
+        assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gv.cpu().numpy(), ov), ("topk", case)
+print(f"{n_cases} cases ok in {time.time() - t0:.1f} s")

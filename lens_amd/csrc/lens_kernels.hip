@@ -738,6 +738,9 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
             } else {
                 for (int d = 0; d < L; ++d) n[u] += counts[(size_t)(i + d) * ldo + jc + d];
             }
+            // candidates are ranked on S = n / L like the reference's argsort, not on n: for sums beyond 2^22 two
+            // different n can round to the same S and must then tie (L = 2, 4: an exact multiply; L = 1: nothing)
+            n[u] = n[u] / (float)L;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -774,7 +777,7 @@ __global__ void __launch_bounds__(256) k_seqmatch_topk(const float *__restrict__
     }
     if (lane < K) {
         tk_idx[(size_t)i * K + lane] = (lj >= 0) ? lj + place_offset : -1;
-        tk_val[(size_t)i * K + lane] = (lj >= 0) ? ln / (float)L : -INFINITY;
+        tk_val[(size_t)i * K + lane] = (lj >= 0) ? ln : -INFINITY;
     }
 }
 

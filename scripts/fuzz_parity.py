@@ -48,5 +48,12 @@ for case in range(n_cases):
         K = int(min(25, 64))
         gi, gv = seqmatch_topk(out, L, K)
         oi, ov = O.topk(S, K)
-        assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gv.cpu().numpy(), ov), ("topk", case)
+        if not (np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gv.cpu().numpy(), ov)):
+            g = gi.cpu().numpy(); gvv = gv.cpu().numpy()
+            bad = np.argwhere((g != oi) | (gvv != ov))
+            r = int(bad[0][0])
+            print("TOPK MISMATCH", dict(case=case, dims=dims, k=k, F=F, P=P, T=T, Q=Q, L=L, K=K, w1s=w1s, w2s=w2s, dens=dens), "row", r)
+            print(" gpu idx", g[r].tolist()); print(" ref idx", oi[r].tolist()); print(" gpu val", gvv[r].tolist()); print(" ref val", ov[r].tolist())
+            print(" S col", S[:, r].tolist()[:80])
+            sys.exit(1)
 print(f"{n_cases} cases ok in {time.time() - t0:.1f} s")

@@ -31,8 +31,8 @@ T_STEPS, ROI, DIMS, SEQ_L, TOPK = 250, 128, 10, 2, 25
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--places", type=int, default=1000, help="reference DB size P (1000 = config 2, 100000 = config 3/4)")
     ap.add_argument("--queries", type=int, default=4096, help="query frames per step per rank-batch")
     ap.add_argument("--shard", choices=["auto", "queries", "db"], default="auto",

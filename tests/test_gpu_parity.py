@@ -421,3 +421,28 @@ def test_event_list_ingest_matches_oracle(O):
     assert np.array_equal(frames.cpu().numpy(), ref)
     with pytest.raises(IndexError):
         frames_from_events(t[:10], np.full(10, roi + 70), y[:10], 1000.0, roi)
+
+
+def test_batch_pipeline_equals_single_stream(O):
+    """Two-stream batch pipelining is host orchestration only: same counts and top-k as one engine, batch by batch."""
+    from lens_amd.pipeline import BatchPipeline
+    from lens_amd.engine import seqmatch_topk
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    w2 = synthetic_database(w2p, 700)
+    batches = [synthetic_frames(q, 128, seed=50 + i).cuda() for i, q in enumerate((96, 64, 33, 96, 1, 80))]
+    eng = _engine(w1, w2, 128, 10, max_batch=96)
+    pipe = BatchPipeline(w1, w2, 128, 10, 250, max_batch=96)
+    counts = pipe.run(batches)
+    tops = pipe.run([b for b in batches if b.shape[0] >= 2], seq_len=2, topk=25)
+    k = 0
+    for b, c in zip(batches, counts):
+        ref = eng.forward_counts(b, carry=False)
+        assert torch.equal(c, ref)
+        if b.shape[0] >= 2:
+            ri, rv = seqmatch_topk(ref, 2, 25)
+            assert torch.equal(tops[k][0], ri) and torch.equal(tops[k][1], rv)
+            k += 1
+    assert np.array_equal(counts[2].cpu().numpy(),
+                          O.forward(batches[2].cpu().numpy(), 10, O.rand_U(250, 128 * 128), np.asarray(w1, np.float32),
+                                    w2.numpy(), carry=False, skip_zero=True))

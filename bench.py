@@ -112,12 +112,20 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # Test hook: LENS_BENCH_SHARED_DEVICE=1 runs every rank on cuda:0 with the gloo backend, so that the N>1 control
+    # flow (sharding, barriers, max-over-ranks timing, gather + merge) can be exercised on a one-GPU box.
+    shared = os.environ.get("LENS_BENCH_SHARED_DEVICE") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from lens_amd.engine import LensEngine, seqmatch_topk, topk_merge
     from lens_amd.dist import shard_rows, gather_topk

@@ -55,3 +55,25 @@ def test_two_rank_sharded_matcher_equals_single_device():
         p.join(300)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+@pytest.mark.parametrize("shard", ["queries", "db"])
+def test_bench_two_ranks_the_way_the_driver_launches_it(shard):
+    """bench.py under torch.distributed.run with 2 ranks.  The box has one GPU, so the test hook
+    LENS_BENCH_SHARED_DEVICE=1 puts both ranks on cuda:0 over gloo; everything else (sharding, barrier + sync
+    bracket, max over ranks, gather + merge for the DB-sharded mode, the single JSON line from rank 0) is the code
+    the 8-GPU run executes."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LENS_BENCH_SHARED_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--queries", "256", "--places", "20000", "--shard", shard, "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert d["scaling"] == ("weak" if shard == "queries" else "strong")
+    assert d["config"]["queries_per_step"] == (512 if shard == "queries" else 256)

@@ -30,19 +30,26 @@ class BatchPipeline:
         self.device = dev
         self._i = 0
 
-    def submit(self, frames, seq_len=None, topk=None):
+    def submit(self, frames, seq_len=None, topk=None, events=None):
         """Enqueue one batch (uint8 [Q,H,W] on the device, Q <= max_batch) on the next stream.  Returns the
         counts [Q,P], or (idx, val) of `seqmatch_topk` when seq_len and topk are given, plus the stream; the
-        tensors are valid once that stream (or `synchronize()`) has been waited for."""
+        tensors are valid once that stream (or `synchronize()`) has been waited for.
+        events: optional 4 torch.cuda.Event, recorded on that stream before / between / after the three kernels."""
         k = self._i % len(self.engines)
         self._i += 1
         eng, st = self.engines[k], self.streams[k]
-        if frames.shape[0] > eng.max_batch:
+        Q = frames.shape[0]
+        if Q > eng.max_batch:
             raise ValueError("BatchPipeline.submit takes at most max_batch queries per call")
         st.wait_stream(torch.cuda.current_stream(self.device))     # frames may have been produced there
         with torch.cuda.stream(st):
-            out = eng.forward_counts(frames, carry=False, check_status=False)
+            if events is not None: events[0].record()
+            eng.feature_events(frames, carry=False)
+            if events is not None: events[1].record()
+            out = eng.output_counts(Q, carry=False)
+            if events is not None: events[2].record()
             res = seqmatch_topk(out, seq_len, topk) if (seq_len and topk) else out
+            if events is not None: events[3].record()
         frames.record_stream(st)
         return res, st
 

@@ -245,6 +245,32 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
             px[i] = (selr[i] >= 0) ? (uint32_t)a.frames[(size_t)q * a.HW + selr[i]] : 0u;
         uint32_t *ev = a.events + (size_t)q * a.cap;
         uint32_t count = 0;
+        constexpr bool ASM_LOOP = (NPL == 2 && FPL == 4 && USE_LDS);
+        if (ASM_LOOP && !a.featspk) {
+            if constexpr (ASM_LOOP) {
+                // hand-scheduled gfx950 step loop (scripts/gen_feature_loop.py); the dynamic LDS block starts at LDS
+                // address 0 (no static __shared__ in this kernel): codes [T][128] bytes, then W1^T [N][256] floats
+                const uint32_t w_base = ((uint32_t)a.T * NP + 15u) & ~15u;
+                uint32_t caddr = (uint32_t)lane;
+                uint32_t cnt = 0;
+                asm volatile(
+#include "feature_loop_n2f4.inc"
+                    : [v0] "+&v"(v[0]), [v1] "+&v"(v[1]), [v2] "+&v"(v[2]), [v3] "+&v"(v[3]), [count] "+&s"(cnt),
+                      [caddr] "+&v"(caddr)
+                    : [px0] "v"(px[0]), [px1] "v"(px[1]), [wa0] "v"(w_base + (uint32_t)lane * 4u),
+                      [wa1] "v"(w_base + 65536u + (uint32_t)lane * 4u),
+                      [fo0] "v"((uint32_t)lane * (uint32_t)a.ev_scale), [fo1] "v"((uint32_t)(64 + lane) * (uint32_t)a.ev_scale),
+                      [fo2] "v"((uint32_t)(128 + lane) * (uint32_t)a.ev_scale), [fo3] "v"((uint32_t)(192 + lane) * (uint32_t)a.ev_scale),
+                      [ev] "s"(ev), [T] "s"(a.T)
+                    : "memory", "vcc", "scc",
+                      "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+                      "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",
+                      "s66", "s67",
+                      "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54",
+                      "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+                count = cnt;
+            }
+        } else {
         uint32_t last_word1 = 0u;   // count word of the latest LAST event (wave-uniform)
         bool flagged = false;       // ... which carries EV_EMPTY_NEXT already
         auto load_codes = [&](int t, uint32_t (&code)[NPL]) {
@@ -349,6 +375,7 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                 count += total;
                 flagged = false;
             }
+        }
         }
         // count is in events (2 words each); pad to a whole chunk of EV_CHUNK events with {0, +1.0f}
         const uint32_t pad = ((uint32_t)EV_CHUNK - (count & (EV_CHUNK - 1))) & (EV_CHUNK - 1);

@@ -10,6 +10,7 @@ from oracle import oracle as O
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"     # larger Q / P / T: several query groups, many tiles, long streams
+HOT = len(sys.argv) > 3 and sys.argv[3] == "hot"     # the shapes of the hand-scheduled loops: 65..128 inputs, 129..256 features
 t0 = time.time()
 for case in range(n_cases):
     dims = int(rng.integers(1, 12))
@@ -20,6 +21,9 @@ for case in range(n_cases):
     P = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 500, 1000, 1300]))
     T = int(rng.choice([1, 2, 7, 16, 33, 100, 250]))
     Q = int(rng.integers(1, 20))
+    if HOT:
+        dims = int(rng.integers(9, 12)); roi = dims * k; N = dims * dims
+        F = int(rng.choice([129, 130, 156, 157, 192, 193, 200, 255, 256]))
     if BIG:
         Q = int(rng.integers(20, 400)); P = int(rng.choice([300, 1000, 2500, 5000])); T = int(rng.choice([100, 250]))
         F = int(rng.choice([64, 156, 200, 312, 400])); dims = int(rng.integers(4, 11)); roi = dims * k; N = dims * dims

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                       "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",
                       "s66", "s67",
                       "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54",
-                      "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+                      "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67");
                 count = cnt;
             }
         } else {

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Benchmark of the LENS hot path on MI355X (contract: see the round prompt / DESIGN.md "Measurement").
+"""Benchmark of the LENS hot path on MI355X (contract: DESIGN.md "Measurement").
 
 A step = one pass of the hot path over one batch of synthetic 128x128 event-count frames already
 resident in HBM:   frames -> rate-coded feature spike streams -> event-driven output layer (place
 database) -> sequence matcher + top-25 per query  [-> RCCL all-gather + merge when the database is
 sharded].  Metric: query event-frames/s (BASELINE.json), whole job.
 
-  python bench.py                                  config 2: 1k-place DB, 4096 queries, 1 GPU
-  python bench.py --places 100000                  config 3: 100k-place DB on one GPU
-  torchrun ... bench.py --gpus 8                   default: queries sharded over ranks (weak, no collective)
-  torchrun ... bench.py --gpus 8 --places 100000 --shard db     config 4: DB sharded, all-gather of top-k
+  python bench.py                              config 3: 100k-place DB, 4096 queries, 1 GPU (+ config 2, carried
+                                               state and the CPU baseline as secondary objects of the same line)
+  python bench.py --places 1000                config 2 as the timed workload
+  torchrun ... bench.py --gpus 8               config 4: the 100k-place DB sharded over the ranks, one all-gather
+                                               of the per-shard top-k per step, merged on every rank
+  torchrun ... bench.py --gpus 8 --shard queries    replicated DB, queries sharded (no collective, weak scaling)
 """
 import argparse
 import json
@@ -23,26 +25,29 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_PEAK_TFLOPS = 157.3     # MI355X fp32, vector == f32-MFMA rate (MI355X_MICROARCH.md, chip-level parameters)
-HBM_PEAK_GBS = 8000.0        # HBM3E spec (same guide)
+FP32_PEAK_TFLOPS = 157.3     # MI355X fp32 vector peak: 256 CUs x 4 SIMDs x 64 lanes x 2 flop (FMA) x 2.4 GHz / 2 cycles
+VALU_ISSUE_PER_NS = 1.2      # one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz
+N_SIMD = 1024
+HBM_PEAK_GBS = 8000.0        # HBM3E spec
 T_STEPS, ROI, DIMS, SEQ_L, TOPK = 250, 128, 10, 2, 25
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--places", type=int, default=1000, help="reference DB size P (1000 = config 2, 100000 = config 3/4)")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--places", type=int, default=100000,
+                    help="reference DB size P (100000 = config 3 on one GPU / config 4 sharded; 1000 = config 2)")
     ap.add_argument("--queries", type=int, default=4096, help="query frames per step per rank-batch")
     ap.add_argument("--shard", choices=["auto", "queries", "db"], default="auto",
-                    help="multi-GPU split: queries (replicated DB, no collective) or db (sharded DB + all-gather)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined-extra", action="store_true", help="skip the informational two-stream measurement")
+                    help="multi-GPU split: db (sharded DB + all-gather of top-k) or queries (replicated DB, no collective)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (baseline and in-run parity)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary objects (config 2, carried state, two-stream pipelining, other kernels)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="2: alternate steps over two HIP streams (lens_amd.pipeline); the per-kernel durations of the "
-                         "roofline are then taken in a serial pass before the timed region.  Default 1 = the contract's "
-                         "single-stream timing with HIP events around every kernel")
+                    help="2: alternate steps over two HIP streams (lens_amd.pipeline); per-kernel durations then come "
+                         "from a serial pass before the timed region")
     return ap.parse_args()
 
 
@@ -52,32 +57,67 @@ def pretrained():
     return sd["feature_layer.w.weight"], sd["output_layer.w.weight"]
 
 
-def cpu_baseline(frames, w1, w2, target_cpu_seconds=15.0):
-    """The CPU oracle (a port of the reference path, dense Linear layers, state reset per query like the
-    GPU run) timed on this host's cores on a bounded sample of the same workload."""
+def host_cores():
+    """Threads for the CPU baseline: the box's CPU share (OMP_NUM_THREADS is set to it there), not the machine's."""
+    env = os.environ.get("OMP_NUM_THREADS")
+    n = int(env) if env and env.isdigit() else (os.cpu_count() or 1)
+    return max(1, min(n, os.cpu_count() or 1, 64))
+
+
+def cpu_baseline_and_parity(frames, w1, w2, gpu_counts, gpu_idx, gpu_val, target_cpu_seconds=15.0):
+    """The CPU oracle (a port of the reference path: dense Linear layers, state reset per query like the GPU run)
+    timed on this host's cores on a bounded sample of the same workload; its output for that sample is then the
+    checker of the GPU results of the same queries (counts of every place, and the top-25 lists)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.lib()
-    cores = min(os.cpu_count() or 1, 64)
+    cores = host_cores()
     U = O.rand_U(T_STEPS, ROI * ROI)
     f = frames.numpy()
     w1n, w2n = w1.numpy(), w2.numpy()
     t0 = time.perf_counter()
-    O.forward(f[:2], DIMS, U, w1n, w2n, carry=False)
-    tq = (time.perf_counter() - t0) / 2
-    n = int(max(cores, min(len(f), target_cpu_seconds / max(tq, 1e-6))))
-    n = min(n, len(f))
+    O.forward(f[:1], DIMS, U, w1n, w2n, carry=False)
+    tq = time.perf_counter() - t0
+    n = int(max(cores, min(len(f), target_cpu_seconds * cores / max(tq, 1e-6))))
+    n = min(n, len(f), 512)
     chunks = [c for c in np.array_split(np.arange(n), cores) if len(c)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(len(chunks)) as ex:       # ctypes releases the GIL inside the C call
-        list(ex.map(lambda c: O.forward(f[c[0]:c[-1] + 1], DIMS, U, w1n, w2n, carry=False), chunks))
+        parts = list(ex.map(lambda c: O.forward(f[c[0]:c[-1] + 1], DIMS, U, w1n, w2n, carry=False), chunks))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "query event-frames/s", "cores": len(chunks), "kind": "port",
+    ref = np.concatenate(parts)
+    base = {"value": n / dt, "unit": "query event-frames/s", "cores": len(chunks), "kind": "port",
             "sample": f"{n} of the {len(f)} synthetic queries against the same {w2.shape[0]}-place DB, "
-                      f"oracle/lens_oracle.c dense path, one thread per core"}
+                      f"oracle/lens_oracle.c dense path, state reset per query, one thread per core"}
+    # the reference's own shape: one query at a time, membrane state carried, one thread (lens/run_model.py:229-246),
+    # on the 1000-place DB so that it stays within seconds
+    w2s = w2n[:1000]
+    m = 24
+    t0 = time.perf_counter()
+    O.forward(f[:m], DIMS, U, w1n, w2s, carry=True)
+    dts = time.perf_counter() - t0
+    base["reference_shaped"] = {"value": m / dts, "unit": "query event-frames/s", "cores": 1,
+                                "sample": f"{m} queries in order, carried state, one thread, 1000-place DB"}
+    oi, ov = O.topk(O.seqmatch(ref, SEQ_L), TOPK)
+    gi, gv = gpu_idx[:n - SEQ_L + 1].cpu().numpy(), gpu_val[:n - SEQ_L + 1].cpu().numpy()
+    parity = {"checker": "oracle/lens_oracle.c on the cpu_baseline sample",
+              "queries": n, "places": int(w2.shape[0]), "spikes_in_sample": float(ref.sum()),
+              "top1_identical": bool(np.array_equal(gi[:, 0], oi[:, 0])),
+              "top25_idx_identical": bool(np.array_equal(gi, oi)),
+              "top25_val_max_abs_diff": float(np.abs(gv - ov).max()),
+              "note": "identical top-25 index lists give an identical Recall@N table for any ground truth "
+                      "(tie policy: score descending, then place index descending)"}
+    if gpu_counts is not None:                     # one GPU holds every place: compare the similarity-matrix rows too
+        got = gpu_counts[:n].cpu().numpy()
+        parity["counts_compared"] = int(ref.size)
+        parity["mismatches"] = int((got != ref).sum())
+    else:
+        parity["mismatches"] = int((gi != oi).sum() + (gv != ov).sum())
+        parity["compared"] = "merged global top-25 lists (each rank holds only its shard's counts)"
+    return base, parity
 
 
-def other_kernel_rooflines(frames_cpu, dev, avg_ms, byts):
+def other_kernel_rooflines(frames_cpu, dev, topk_ms, topk_bytes):
     """HBM rooflines of the memory-bound rows of the path, measured once outside the timed region:
     a1 event accumulation (4 B/event in + H*W B/frame out) and the in-step seq-match/top-k kernel."""
     from lens_amd.engine import accumulate_events
@@ -98,9 +138,81 @@ def other_kernel_rooflines(frames_cpu, dev, avg_ms, byts):
     res = {"k_accumulate_events": {"bound": "hbm", "frames": nf, "events": int(xy.shape[0]), "avg_launch_ms": ms,
                                    "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-    ach = byts[2] / (avg_ms[2] * 1e-3) / 1e9
-    res["k_seqmatch_topk"] = {"bound": "hbm", "avg_launch_ms": avg_ms[2], "achieved": ach, "peak": HBM_PEAK_GBS,
+    ach = topk_bytes / (topk_ms * 1e-3) / 1e9
+    res["k_seqmatch_topk"] = {"bound": "hbm", "avg_launch_ms": topk_ms, "achieved": ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    return res
+
+
+def stream_stats(eng, Q):
+    """Executed work of the event-driven output kernel, counted from the spike streams: event slots per query and
+    integrate-and-fire updates per query (time steps without feature spikes are not in the stream)."""
+    nw = eng.nwords[:Q]
+    words = float(nw.float().mean().item())
+    cw = eng.events[:Q].view(Q, -1, 2)[:, :, 1]
+    steps = 0.0
+    for q0 in range(0, Q, 512):                                  # bounded temporaries: the workspace is worst-case sized
+        c = cw[q0:q0 + 512, :int(nw.max().item()) // 2 + 1]
+        valid = torch.arange(c.shape[1], device=c.device)[None, :] < (nw[q0:q0 + 512, None] // 2)
+        steps += float(((c < 0) & valid).sum().item())
+    return words, words / 2.0, steps / Q
+
+
+def time_steps(step, n, events=None):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        step(events[k] if events is not None else None)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def secondary_config2(w1, w2p, frames, dev, steps):
+    """Config 2 (1000-place DB, same queries) from the same run: reset-mode rate and per-kernel times, then the
+    reference's own semantics (state carried from query to query, lens/run_model.py:234-242) on 256 queries as one
+    carried stream and as 16 independent carried streams."""
+    from lens_amd.engine import LensEngine, seqmatch_topk
+    from lens_amd.synthetic import synthetic_database
+    Q = frames.shape[0]
+    eng = LensEngine(w1, synthetic_database(w2p, 1000), ROI, DIMS, T_STEPS, device=dev, max_batch=Q)
+    names = ["k_feature_events", "k_output_counts", "k_seqmatch_topk"]
+
+    def step(evs=None):
+        if evs is not None: evs[0].record()
+        eng.feature_events(frames, carry=False)
+        if evs is not None: evs[1].record()
+        counts = eng.output_counts(Q, carry=False)
+        if evs is not None: evs[2].record()
+        seqmatch_topk(counts, SEQ_L, TOPK)
+        if evs is not None: evs[3].record()
+
+    for _ in range(3):
+        step()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    dt = time_steps(step, steps, evs)
+    ms = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i in range(3)]
+    res = {"config2": {"workload": f"config 2: 1000-place DB, {Q} queries per step, state reset per query",
+                       "value": Q * steps / dt, "unit": "query event-frames/s", "ms_per_step": dt / steps * 1e3,
+                       "steps": steps, "kernels_ms": dict(zip(names, ms))}}
+    carry = {}
+    qc = min(256, Q)
+    for n_streams in (1, 16):
+        eng.reset_state(n_streams=n_streams)
+        eng.forward_counts(frames[:qc], carry=True)             # warm-up (also sizes the workspace)
+        reps = 3
+        eng.reset_state(n_streams=n_streams)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c = eng.forward_counts(frames[:qc], carry=True)
+            seqmatch_topk(c, SEQ_L, TOPK)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t0) / reps
+        carry[f"streams_{n_streams}"] = {"value": qc / dtc, "unit": "query event-frames/s", "ms_per_batch": dtc * 1e3,
+                                         "queries": qc}
+    carry["note"] = ("reference semantics: membrane state carried across queries, each stream strictly sequential in "
+                     "the query index; 1000-place DB; streams_1 is the drop-in for lens/run_model.py:229-246")
+    res["carry_mode"] = carry
     return res
 
 
@@ -119,6 +231,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -127,8 +240,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from lens_amd.engine import LensEngine, seqmatch_topk, topk_merge
-    from lens_amd.dist import shard_rows, gather_topk
+    from lens_amd.engine import LensEngine, seqmatch_topk
+    from lens_amd.dist import shard_rows, ShardedStep
     from lens_amd.synthetic import synthetic_frames, synthetic_database
 
     shard = a.shard
@@ -140,6 +253,7 @@ def main():
     w1, w2p = pretrained()
     w2 = synthetic_database(w2p, a.places)
     Q = a.queries
+    sharded = None
     if shard == "queries":
         frames_cpu = synthetic_frames(Q, ROI, seed=1234 + rank)     # every rank its own queries
         eng = LensEngine(w1, w2, ROI, DIMS, T_STEPS, device=dev, max_batch=Q)
@@ -149,12 +263,17 @@ def main():
         frames_cpu = synthetic_frames(Q, ROI, seed=1234)            # same queries, DB split over ranks
         r0, r1, n_places, offset = shard_rows(a.places, SEQ_L, rank, world)
         eng = LensEngine(w1, w2[r0:r1], ROI, DIMS, T_STEPS, device=dev, max_batch=Q)
+        sharded = ShardedStep(eng, SEQ_L, TOPK, n_places, offset, Q, world)
         total_queries = Q
     frames = frames_cpu.to(dev)
 
     names = ["k_feature_events", "k_output_counts", "k_seqmatch_topk"]
+    last = {}
 
     def step(evs=None):
+        if sharded is not None:
+            last["res"] = sharded.submit(frames, evs)
+            return
         if evs is not None: evs[0].record()
         eng.feature_events(frames, carry=False)
         if evs is not None: evs[1].record()
@@ -162,10 +281,8 @@ def main():
         if evs is not None: evs[2].record()
         idx, val = seqmatch_topk(counts, SEQ_L, TOPK, n_places=n_places, place_offset=offset)
         if evs is not None: evs[3].record()
-        if shard == "db":
-            ia, va = gather_topk(idx, val)
-            idx, val = topk_merge(ia, va)
-        return idx, val
+        last["res"] = (idx, val)
+        last["counts"] = counts
 
     for _ in range(a.warmup):
         step()
@@ -187,73 +304,75 @@ def main():
     t0 = time.perf_counter()
     if pipe is None:
         for k in range(a.steps):
-            idx, val = step(events[k])
+            step(events[k])
     else:
         for k in range(a.steps):
-            (idx, val), _ = pipe.submit(frames, SEQ_L, TOPK)
+            pipe.submit(frames, SEQ_L, TOPK)
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # informational extra (not `value`): the same steps alternated over two HIP streams
-    piped_ms = None
-    if pipe is None and shard != "db" and not a.no_pipelined_extra:
-        from lens_amd.pipeline import BatchPipeline
-        p2 = BatchPipeline(w1, w2, ROI, DIMS, T_STEPS, device=dev, max_batch=Q)
-        for _ in range(max(2, a.warmup)):
-            p2.submit(frames, SEQ_L, TOPK)
-        p2.synchronize()
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for k in range(a.steps):
-            p2.submit(frames, SEQ_L, TOPK)
-        torch.cuda.synchronize()
-        piped_ms = (time.perf_counter() - tp) / a.steps * 1e3
-        del p2
+    multi = None
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        cpu = shared                                                 # gloo: CPU tensors only
+        tdev = "cpu" if cpu else dev
+        tt = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    eng.check_status()
+        mine = torch.tensor([float(rank), my_elapsed], device=tdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        multi = {"ranks_seen": sorted(int(t[0].item()) for t in allr),
+                 "per_rank_elapsed_s": [float(t[1].item()) for t in sorted(allr, key=lambda t: float(t[0].item()))],
+                 "backend": dist.get_backend()}
+        if sharded is not None:
+            multi["gather_merge_ms"] = sharded.gather_merge_ms()
+            multi["overlap"] = "all-gather + merge of step i run on a second stream beside the kernels of step i+1"
 
     if rank == 0:
         ms = [[ev[i].elapsed_time(ev[i + 1]) for ev in events] for i in range(3)]
         avg_ms = [float(np.mean(m)) for m in ms]
         dom = int(np.argmax(avg_ms))
         P_local = eng.P
-        words = float(eng.nwords[:Q].float().mean().item())
-        # algorithmic work per launch (DESIGN.md "Measurement"): dense-equivalent FLOPs of the Linear layers
-        flops = [2.0 * T_STEPS * eng.N * eng.F * Q, 2.0 * T_STEPS * eng.F * P_local * Q, None]
-        # algorithmic bytes per launch for the memory-side kernels
-        byts = [Q * (ROI * ROI + 4.0 * words), None, Q * (4.0 * P_local + 8.0 * TOPK)]   # counts are read once from HBM
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get(f"P{a.places}_Q{Q}", {}).get(names[dom])
-        if flops[dom] is not None:
-            ach = flops[dom] / (avg_ms[dom] * 1e-3) / 1e12
-            # executed work of the event-driven kernel: one FMA per (event slot, place) + ~8 flops of IAF per (step, place)
-            ev_slots = words / 2.0
-            # integrate-and-fire updates actually executed: steps without feature spikes are not in the stream
-            cw = eng.events[:Q].view(Q, -1, 2)[:, :, 1]
-            valid = torch.arange(cw.shape[1], device=cw.device)[None, :] < (eng.nwords[:Q, None] // 2)
-            steps_exec = float(((cw < 0) & valid).sum().item()) / Q
-            exe = (2.0 * ev_slots + 8.0 * steps_exec) * P_local * Q if dom == 1 else flops[dom]
-            exe_ach = exe / (avg_ms[dom] * 1e-3) / 1e12
-            roof = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
-                    "executed_achieved": exe_ach, "executed_frac": exe_ach / FP32_PEAK_TFLOPS,
-                    "note": "peak = fp32 (vector rate == f32 MFMA rate on MI355X). achieved/frac count the ALGORITHMIC "
-                            "dense-equivalent FLOPs 2*T*F*P per query (SURVEY 8d); the kernel is event-driven and skips "
-                            "zero spikes, so this fraction can exceed 1. executed_* count the work actually issued "
-                            "(2 flops per event slot and place + 8 per executed IAF update; steps without feature spikes are "
-                            "dropped from the stream) -- the kernel-quality figure.",
-                    "avg_launch_ms": avg_ms[dom]}
+        words, ev_slots, steps_exec = stream_stats(eng, Q)
+        topk_bytes = Q * (4.0 * P_local + 8.0 * TOPK)              # the counts matrix is read once
+        if dom == 1:
+            # Executed work of the event-driven output kernel.  Per (event slot, place) one accumulate, counted as an
+            # FMA (2 flops; single-spike events execute it as a plain add, 1 flop); per (executed step, place) ~8 flops
+            # of integrate-and-fire (add, threshold test, 2-FMA clip, spike path).  Time steps without feature spikes
+            # and the ~97 % zero spikes of the dense formulation are skipped exactly (fmaf(0, w, acc) == acc).
+            exe = (2.0 * ev_slots + 8.0 * steps_exec) * P_local * Q
+            exe1 = (1.0 * ev_slots + 8.0 * steps_exec) * P_local * Q
+            dense = 2.0 * T_STEPS * eng.F * P_local * Q
+            sec = avg_ms[dom] * 1e-3
+            roof = {"kernel": names[dom], "bound": "valu", "achieved": exe / sec / 1e12, "peak": FP32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": exe / sec / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": avg_ms[dom],
+                    "executed_flop_per_launch": exe, "event_slots_per_query": ev_slots,
+                    "executed_steps_per_query": steps_exec,
+                    "frac_add_as_one_flop": exe1 / sec / 1e12 / FP32_PEAK_TFLOPS,
+                    "dense_equivalent": {"flop_per_launch": dense, "tflops": dense / sec / 1e12,
+                                         "speedup_over_fp32_peak": dense / sec / 1e12 / FP32_PEAK_TFLOPS,
+                                         "note": "2*T*F*P per query; not a roofline fraction, the kernel skips the zeros"},
+                    "counting": "frac = executed FLOPs / launch time / fp32 vector peak; executed = (2 per event slot "
+                                "+ 8 per executed integrate-and-fire step) per place; the kernel issues no MFMA "
+                                "(a dense f32-MFMA variant exists for comparison and is 26x slower)"}
         else:
+            byts = [Q * (ROI * ROI + 4.0 * words), None, topk_bytes]
             ach = byts[dom] / (avg_ms[dom] * 1e-3) / 1e9
             roof = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms[dom]}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms[dom]}
+        ppath = os.path.join(ROOT, "profiles", "pmc.json")
+        if os.path.exists(ppath):
+            with open(ppath) as fh:
+                pm = json.load(fh).get(f"P{P_local}_Q{Q}", {}).get(names[dom])
+            if pm:
+                roof["traffic"] = pm.get("hbm_bytes_per_launch")
+                roof["offline_profile"] = dict(pm, note="rocprofv3 --pmc passes of this workload committed under "
+                                               "profiles/ (not measured in this run); valu_issue_frac = SQ_INSTS_VALU "
+                                               "/ (1024 SIMDs x launch time x 1.2 VALU/ns)")
+        cfg = 2 if a.places == 1000 else (3 if world == 1 else (4 if shard == "db" else 3))
         line = {
             "metric": "query event-frames/sec vs ref-DB size; Recall@1 parity with reference",
             "value": total_queries * a.steps / elapsed,
@@ -265,24 +384,41 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"config {2 if a.places == 1000 else 3 if world == 1 else 4}: pretrained LENS feature layer "
-                                   f"(IN100/FN200), synthetic {ROI}x{ROI} event frames, {a.places}-place reference DB, "
-                                   f"state reset per query, T={T_STEPS}, L={SEQ_L}, top-{TOPK}",
+            "config": {"workload": f"config {cfg}: pretrained LENS feature layer (IN100/FN200), synthetic {ROI}x{ROI} "
+                                   f"event frames, {a.places}-place reference DB"
+                                   + (f" sharded over {world} GPUs" if shard == "db" else "")
+                                   + f", {total_queries} queries per step, state reset per query, T={T_STEPS}, "
+                                   f"L={SEQ_L}, top-{TOPK}",
                        "places": a.places, "queries_per_step": total_queries, "shard": shard if world > 1 else "none",
-                       "streams": a.streams,
-                       "feature_spike_words_per_query": words},
+                       "streams": a.streams, "feature_spike_words_per_query": words},
             "kernels_ms": dict(zip(names, avg_ms)),
             "roofline": roof,
         }
-        if piped_ms is not None:
-            line["two_stream_pipelining"] = {
-                "ms_per_step": piped_ms, "value": Q * 1e3 / piped_ms * world, "unit": "query event-frames/s",
-                "note": "informational, rank 0's own rate x ranks: the same steps alternated over two HIP streams "
-                        "(lens_amd.pipeline, identical results); not `value`, whose single-stream timing keeps the "
-                        "per-kernel HIP-event durations of `roofline` meaningful.  bench.py --streams 2 times this mode."}
-        line["other_kernels"] = other_kernel_rooflines(frames_cpu, dev, avg_ms, byts)
+        if multi is not None:
+            line["multi_gpu"] = multi
+        if not a.no_extras and world == 1:
+            line["other_kernels"] = other_kernel_rooflines(frames_cpu, dev, avg_ms[2], topk_bytes)
+            if a.places != 1000:
+                line["other_configs"] = secondary_config2(w1, w2p, frames, dev, min(a.steps, 20))
+            if pipe is None:
+                from lens_amd.pipeline import BatchPipeline
+                p2 = BatchPipeline(w1, w2, ROI, DIMS, T_STEPS, device=dev, max_batch=Q)
+                for _ in range(2):
+                    p2.submit(frames, SEQ_L, TOPK)
+                p2.synchronize()
+                n2 = min(a.steps, 10)
+                dt2 = time_steps(lambda _e: p2.submit(frames, SEQ_L, TOPK), n2)
+                line["two_stream_pipelining"] = {
+                    "ms_per_step": dt2 / n2 * 1e3, "value": Q * n2 / dt2, "unit": "query event-frames/s",
+                    "note": "informational: the same steps alternated over two HIP streams (lens_amd.pipeline, identical "
+                            "results); `value` is timed on one stream so that the per-kernel durations are those of the "
+                            "kernels alone"}
+                del p2
         if not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(frames_cpu, w1, w2 if shard == "queries" else w2)
+            gi, gv = last["res"]
+            base, parity = cpu_baseline_and_parity(frames_cpu, w1, w2, last.get("counts"), gi, gv)
+            line["cpu_baseline"] = base
+            line["parity"] = parity
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -9,14 +9,19 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
-SO_PATH = os.path.join(_PKG, "liblens_amd.so")
+# LENS_AMD_SO selects another in-tree build of the same sources (kernel experiments); the default is the product.
+SO_PATH = os.environ.get("LENS_AMD_SO") or os.path.join(_PKG, "liblens_amd.so")
 SRC = os.path.join(_PKG, "csrc", "lens_kernels.hip")
+INCLUDES = [os.path.join(_PKG, "csrc", "feature_loop_n2f4.inc")]     # textually included by SRC
 HEADER = os.path.join(ROOT, "include", "lens_amd.h")
 
 # -ffp-contract=off: the only fused operations are the explicit fmaf calls (numerics contract).
-# -fno-slp-vectorize: packed f32 VALU ops run at half rate on gfx950 (no gain over two plain ops) and
-#   cannot take the |x| source modifier the event loop relies on.
+# -fno-slp-vectorize / -packed-fp32-ops: no packed f32 VALU (v_pk_add/mul/fma_f32) anywhere in the device code:
+#   they have no rate advantage on gfx950, cannot take the |x| source modifier the event loop relies on, and
+#   the target feature is switched off outright so that no optimisation pass can form them (the host pass of
+#   hipcc does not know the feature and says so in a harmless warning).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+               "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
                "-fPIC", "-shared", "-Wall"]
 
 _c_p = ctypes.c_void_p
@@ -54,8 +59,8 @@ class LensAmdError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Compile lens_amd/csrc/lens_kernels.hip -> lens_amd/liblens_amd.so (gfx950)."""
-    if (not force and os.path.exists(SO_PATH)
-            and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(SRC), os.path.getmtime(HEADER))):
+    newest = max(os.path.getmtime(f) for f in [SRC, HEADER] + INCLUDES)
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH, SRC]

@@ -180,7 +180,7 @@ class LensEngine:
         _lib.check(st, "lens_output_counts_dense")
         return out
 
-    def forward_counts(self, frames, carry=False, n_groups=0, check_status=True):
+    def forward_counts(self, frames, carry=False, n_groups=0):
         """The query loop of LENS.evaluate (lens/run_model.py:229-246) for a batch of frames:
         uint8 [Q,H,W] -> similarity-matrix rows float32 [Q,P].  carry=True integrates the queries
         in order with the membrane state carried across them (and across calls)."""
@@ -193,21 +193,15 @@ class LensEngine:
             fr = frames[q0:q0 + step]
             self.feature_events(fr, carry=carry)
             self.output_counts(fr.shape[0], carry=carry, n_groups=n_groups, out=out[q0:q0 + step])
-        if check_status:
-            self.check_status()
         return out
-
-    def check_status(self):
-        """Kept for API stability: the spike stream now carries full float32 counts, nothing can overflow."""
-        return None
 
     # ---- matching ----------------------------------------------------------------------
     def seqmatch(self, counts, L):
         """lens/run_model.py:248-252, query-major: S[i][j] float32 [Q-L+1, P-L+1]."""
         return seqmatch(counts, L)
 
-    def seqmatch_topk(self, counts, L, K, n_places=None, place_offset=0):
-        return seqmatch_topk(counts, L, K, n_places=n_places, place_offset=place_offset)
+    def seqmatch_topk(self, counts, L, K, n_places=None, place_offset=0, out=None):
+        return seqmatch_topk(counts, L, K, n_places=n_places, place_offset=place_offset, out=out)
 
 
 def seqmatch(counts, L):
@@ -220,29 +214,39 @@ def seqmatch(counts, L):
     return S
 
 
-def seqmatch_topk(counts, L, K, n_places=None, place_offset=0):
+def _pair_out(out, shape, device):
+    """(int32 idx, float32 val) result buffers of `shape`: the caller's (checked) or fresh ones."""
+    if out is None:
+        return (torch.empty(shape, dtype=torch.int32, device=device),
+                torch.empty(shape, dtype=torch.float32, device=device))
+    idx, val = out
+    assert idx.dtype == torch.int32 and val.dtype == torch.float32 and idx.is_cuda and val.is_cuda
+    assert tuple(idx.shape) == tuple(shape) and tuple(val.shape) == tuple(shape)
+    assert idx.is_contiguous() and val.is_contiguous()
+    return idx, val
+
+
+def seqmatch_topk(counts, L, K, n_places=None, place_offset=0, out=None):
     """Sequence matcher + top-K per query (ties -> larger place index). counts [Q, ld] device.
-    Returns idx int32 [Q-L+1,K], val float32 [Q-L+1,K]."""
+    Returns idx int32 [Q-L+1,K], val float32 [Q-L+1,K] (written into `out` = (idx, val) when given)."""
     _need_cuda(counts, "counts")
     assert counts.dtype == torch.float32 and counts.is_contiguous()
     Q, ld = counts.shape
     if n_places is None:
         n_places = ld - L + 1
-    idx = torch.empty((Q - L + 1, K), dtype=torch.int32, device=counts.device)
-    val = torch.empty((Q - L + 1, K), dtype=torch.float32, device=counts.device)
+    idx, val = _pair_out(out, (Q - L + 1, K), counts.device)
     st = _lib.lib().lens_seqmatch_topk(_ptr(counts), Q, ld, n_places, L, K, place_offset, _ptr(idx), _ptr(val), _stream())
     _lib.check(st, "lens_seqmatch_topk")
     return idx, val
 
 
-def topk_merge(idx_in, val_in):
+def topk_merge(idx_in, val_in, out=None):
     """Merge per-shard lists [R,Qs,K] -> [Qs,K] with the same ordering rule."""
     _need_cuda(idx_in, "idx_in")
     R, Qs, K = idx_in.shape
     assert idx_in.dtype == torch.int32 and val_in.dtype == torch.float32
     idx_in = idx_in.contiguous(); val_in = val_in.contiguous()
-    idx = torch.empty((Qs, K), dtype=torch.int32, device=idx_in.device)
-    val = torch.empty((Qs, K), dtype=torch.float32, device=idx_in.device)
+    idx, val = _pair_out(out, (Qs, K), idx_in.device)
     st = _lib.lib().lens_topk_merge(_ptr(idx_in), _ptr(val_in), R, Qs, K, _ptr(idx), _ptr(val), _stream())
     _lib.check(st, "lens_topk_merge")
     return idx, val

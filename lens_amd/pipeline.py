@@ -62,5 +62,3 @@ class BatchPipeline:
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
-        for e in self.engines:
-            e.check_status()

@@ -34,14 +34,18 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 5
+#define LENS_AMD_ABI_VERSION 6
+
+/* Size of the library-owned device array behind lens_forward_counts_static (held once per GPU in use). */
+#define LENS_STATIC_SCRATCH_BYTES (64u << 20)
 
 enum {
     LENS_OK = 0,
     LENS_ERR_NULL = -1,        /* a required pointer is NULL */
     LENS_ERR_SIZE = -2,        /* a size / stride argument is out of range */
     LENS_ERR_UNSUPPORTED = -3, /* valid request outside what the kernels implement (see each function) */
-    LENS_ERR_ALIGN = -4        /* a pointer / leading dimension violates the stated alignment */
+    LENS_ERR_ALIGN = -4,       /* a pointer / leading dimension violates the stated alignment */
+    LENS_ERR_SCRATCH = -5      /* lens_forward_counts_static: the batch does not fit the static scratch array */
 };
 
 /* ABI version of the loaded library (== LENS_AMD_ABI_VERSION it was built with). */
@@ -134,6 +138,26 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
                        const float *d_w2t, int F, int P, int ldw2,
                        float *d_vout, int ldv, int n_groups, int carry,
                        float *d_counts, int ldo, void *stream);
+
+/*
+ * lens_feature_events followed by lens_output_counts, with the spike-stream workspace (`events`, `nwords`) in
+ * a library-owned static device array instead of caller memory.  It has no counterpart in the reference: it
+ * exists for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  The call allocates and frees nothing and synchronises nothing; the caller
+ * still passes every input and output (arguments as in the two calls above; n_streams / carry apply to both
+ * layers, d_vfeat [n_streams][F] and d_vout [n_streams][ldv] are the carried state when carry != 0).
+ * Limit: 256-byte-rounded 4*Q + 4*Q*lens_event_capacity_words(T, F) <= LENS_STATIC_SCRATCH_BYTES (64 MiB: 167
+ *        queries at T = 250, F = 200), otherwise LENS_ERR_SCRATCH and nothing is enqueued.
+ * The array's device address is resolved on the first call on each device (hipGetSymbolAddress); make that first
+ * call -- Q = 0 is enough -- outside any stream capture.  Every call on a GPU shares that GPU's array, which
+ * keeps the previous call's contents (nothing in it has to start at zero: each call writes every word it later
+ * reads): calls that overlap on one GPU (two streams, two host threads) race.
+ */
+int lens_forward_counts_static(const uint8_t *d_frames, int Q, int HW, const int32_t *d_sel, int N,
+                               const uint8_t *d_codes, int T, const float *d_w1t, int F, int ldw1,
+                               const float *d_w2t, int P, int ldw2,
+                               float *d_vfeat, float *d_vout, int ldv, int n_streams, int carry,
+                               float *d_counts, int ldo, void *stream);
 
 /*
  * Sequence matcher, full matrix.  Replaces lens/run_model.py:248-252:

@@ -38,6 +38,8 @@ SIGNATURES = {
     "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
                                  _c_p, _i, _c_p, _i, _c_p, _c_p]),
     "lens_output_counts": (_i, [_c_p, _i, _c_p, _i, _c_p, _i, _i, _i, _c_p, _i, _i, _i, _c_p, _i, _c_p]),
+    "lens_forward_counts_static": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
+                                        _c_p, _c_p, _i, _i, _i, _c_p, _i, _c_p]),
     "lens_seqmatch": (_i, [_c_p, _i, _i, _i, _i, _c_p, _i, _c_p]),
     "lens_seqmatch_topk": (_i, [_c_p, _i, _i, _i, _i, _i, _i, _c_p, _c_p, _c_p]),
     "lens_topk_merge": (_i, [_c_p, _c_p, _i, _i, _i, _c_p, _c_p, _c_p]),
@@ -50,7 +52,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class LensAmdError(RuntimeError):

@@ -195,6 +195,23 @@ class LensEngine:
             self.output_counts(fr.shape[0], carry=carry, n_groups=n_groups, out=out[q0:q0 + step])
         return out
 
+    def forward_counts_static(self, frames, out, carry=False):
+        """forward_counts through lens_forward_counts_static: the spike-stream workspace is the library's static
+        device array, and this call allocates nothing (the caller passes `out`, float32 [Q,P] on the device).
+        For callers that cannot allocate; the batch must fit the array (LensAmdError otherwise)."""
+        _need_cuda(frames, "frames"); _need_cuda(out, "out")
+        assert frames.dtype == torch.uint8 and frames.is_contiguous()
+        Q = frames.shape[0]
+        assert Q == 0 or frames[0].numel() == self.HW, "frame size does not match roi_dim"
+        assert out.dtype == torch.float32 and out.shape == (Q, self.P) and out.is_contiguous()
+        st = _lib.lib().lens_forward_counts_static(
+            _ptr(frames), Q, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
+            _ptr(self.w1t), self.F, self.F, _ptr(self.w2t), self.P, self.ldw2,
+            _ptr(self.v_feat), _ptr(self.v_out), self.P, self.n_streams if carry else 0, int(carry),
+            _ptr(out), self.P, _stream())
+        _lib.check(st, "lens_forward_counts_static")
+        return out
+
     # ---- matching ----------------------------------------------------------------------
     def seqmatch(self, counts, L):
         """lens/run_model.py:248-252, query-major: S[i][j] float32 [Q-L+1, P-L+1]."""

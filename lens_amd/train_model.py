@@ -21,13 +21,16 @@ from .dataset import CustomImageDataset
 from .loggers import model_logger
 
 
-def anneal_schedule(layer, T):
-    """(eta_ip, eta_stdp) in effect at each of the T steps (train_model.py:120-128,150-152,179-181): the
-    constructor values at step 0; after every 10th step eta = init * ((T - mod)/T)**2, init_itp = 2*eta_stdp."""
+def anneal_schedule(layer, n_steps, horizon=None):
+    """(eta_ip, eta_stdp) in effect at each of the n_steps steps (train_model.py:120-128,150-152,179-181): the
+    constructor values at step 0; after every 10th step eta = init * ((T - mod)/T)**2, init_itp = 2*eta_stdp.
+    T (`horizon`) is the reference's self.T = reference_places * epochs (train_model.py:143), which exceeds the
+    number of steps actually taken when the CSV holds fewer rows than --reference_places."""
+    T = n_steps if horizon is None else horizon
     eip, est = layer.eta_ip.clone().float(), layer.eta_stdp.clone().float()
     init_itp, init_stdp = layer.eta_stdp.detach().float() * 2, layer.eta_stdp.detach().float()
-    out_ip, out_st = torch.zeros(T), torch.zeros(T)
-    for mod in range(T):
+    out_ip, out_st = torch.zeros(n_steps), torch.zeros(n_steps)
+    for mod in range(n_steps):
         out_ip[mod], out_st[mod] = eip, est
         if mod % 10 == 0:
             pt = pow(float(T - mod) / T, 2)
@@ -101,8 +104,7 @@ class LENS_Trainer(nn.Module):
         if orders is None:
             orders = [list(torch.utils.data.RandomSampler(range(S))) for _ in range(epochs)]
         order = torch.tensor(np.asarray(orders).reshape(-1), dtype=torch.int32)
-        T = order.numel()
-        eta_ip, eta_stdp, last_ip, last_stdp = anneal_schedule(layer, T)
+        eta_ip, eta_stdp, last_ip, last_stdp = anneal_schedule(layer, order.numel(), horizon=self.T)
 
         table = x_table.to(dev)
         n_in = table.shape[1]

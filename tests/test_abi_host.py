@@ -267,3 +267,24 @@ def test_event_windows_skip_empty_windows(tmp_path):
     p.write_text("128 128\n100 3 4 1\n250.5 7 8 0\n")
     tt, x, y, pol = load_event_text(str(p))
     assert tt.tolist() == [100.0, 250.5] and x.tolist() == [3, 7] and y.tolist() == [4, 8] and pol.tolist() == [1, 0]
+
+
+def test_training_pad_covers_wide_layers_and_short_csv_annealing():
+    """Fan-ins up to 1024 have a kernel instantiation (e.g. --dims 20 => 400 inputs, 800 features); the learning-rate
+    annealing horizon is reference_places * epochs (lens/train_model.py:124-125,143) even when fewer steps are taken."""
+    import torch
+    from lens_amd import _lib
+    from lens_amd.train_model import anneal_schedule
+    L = _lib.lib()
+    assert [L.lens_train_in_pad(n) for n in (1, 64, 65, 200, 256, 257, 800, 1024, 1025)] == \
+        [64, 64, 128, 208, 256, 512, 1024, 1024, 0]
+
+    class Layer:
+        eta_ip = torch.tensor(0.02)
+        eta_stdp = torch.tensor(0.01)
+    ip, st, _, _ = anneal_schedule(Layer, 25, horizon=100)
+    assert float(st[0]) == float(torch.tensor(0.01)) and float(st[1]) == float(torch.mul(torch.tensor(0.01), pow(100 / 100, 2)))
+    assert float(st[11]) == float(torch.mul(torch.tensor(0.01), pow(float(100 - 10) / 100, 2)))
+    assert float(ip[21]) == float(torch.mul(torch.tensor(0.01) * 2, pow(float(100 - 20) / 100, 2)))
+    full, _, _, _ = anneal_schedule(Layer, 25)
+    assert float(full[21]) == float(torch.mul(torch.tensor(0.01) * 2, pow(float(25 - 20) / 25, 2)))

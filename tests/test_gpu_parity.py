@@ -359,6 +359,8 @@ def test_stream_consumer_dropped_steps(O, F):
         [[(0, 1)], [], [], [(0, 1)], [(1, big)], [], [(1, 1)], [(0, 1), (1, 1)], [], [(0, 1)], [], [], [], [(0, 1)]],
         [[], [], [], [(1, 1)], [(0, 1)], [], [(0, 1)], [], [(0, 1)], [], [(0, 1)], [], [(0, 2), (1, 5)], []],
         [[(0, 1)]] * 3 + [[]] * 30 + [[(0, 1), (1, 1)]] * 17 + [[]],
+        # odd counts >= 2^23: the mantissa LSB is part of the count there, not the "empty steps follow" flag
+        [[(1, big + 1)], [(0, 1)], [(0, big + 3), (1, big + 5)], [], [(1, 1)], [(0, 2 * big + 2)], [(1, big + 7)], []],
     ]
     T = max(len(q) for q in queries)
     queries = [q + [[]] * (T - len(q)) for q in queries]

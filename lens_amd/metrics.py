@@ -1,36 +1,43 @@
-"""Recall@K as LENS evaluates it (behavioural restatement of `recallAtK`,
-lens/src/metrics.py:183-226; written from its behaviour, no text taken from that file).
+"""Host-side mirror of the two evaluation entry points of LENS, `recallAtK` and `createPR`
+(lens/src/metrics.py:183-226 and :21-139).
 
-S and GT are [places, queries].  Queries (columns) without any positive in GT are dropped.  For the
-rest, the K most similar places are the last K rows of an ascending argsort of the column; the
-query counts as recalled if any of them is a GT positive.  `sort_kind=None` is numpy's default
-(unstable) sort, which is what the reference calls; "stable" gives the explicit tie policy of the
-GPU top-k path (ties -> larger place index).
+What is kept from the reference on purpose, because callers and the parity tests see it: the function and
+argument names, the assertion messages, the returned values (Recall@K as a float; the P and R lists starting
+with the conventional point P=1, R=0) and the name of the figure file.  What is this build's own: the
+arithmetic is restated in vectorised numpy (the precision/recall sweep counts hits with a sort and a binary
+search instead of one pass over the matrix per threshold) and the figure is drawn by `_draw_matches` below.
+
+S and GT are [places, queries].  Recall@K: queries (columns) without any positive in GT are dropped; for the
+rest, the K most similar places are the last K rows of an ascending argsort of the column, and the query counts
+as recalled if any of them is a GT positive.  `sort_kind=None` is numpy's default (unstable) sort, which is what
+the reference calls -- with integer spike counts ties are the norm, so the tie order is part of the result;
+"stable" gives the explicit tie policy of the GPU top-k path (ties -> larger place index).
 """
 import os
 
 import numpy as np
 
 
-def recallAtK(S_in, GThard, GTsoft=None, K=1, sort_kind=None):
-    assert S_in.shape == GThard.shape, "S_in and GThard must have the same shape"
+def _checked(S_in, GThard, GTsoft, what):
+    assert S_in.shape == GThard.shape, f"{what} must have the same shape"
     if GTsoft is not None:
         assert S_in.shape == GTsoft.shape, "S_in and GTsoft must have the same shape"
-    assert S_in.ndim == 2, "S_in, GThard and GTsoft must be two-dimensional"
-    assert K >= 1, "K must be >=1"
     gt = GThard.astype(bool)
     S = S_in.copy()
     if GTsoft is not None:
-        soft = GTsoft.astype(bool)
-        S[soft & ~gt] = S.min()          # soft-only matches are ignored during evaluation
-    has_match = gt.sum(axis=0) > 0
-    S = S[:, has_match]
-    gt = gt[:, has_match]
+        S[GTsoft.astype(bool) & ~gt] = S.min()          # soft-only matches are ignored during evaluation
+    return S, gt
+
+
+def recallAtK(S_in, GThard, GTsoft=None, K=1, sort_kind=None):
+    S, gt = _checked(S_in, GThard, GTsoft, "S_in and GThard")
+    assert S_in.ndim == 2, "S_in, GThard and GTsoft must be two-dimensional"
+    assert K >= 1, "K must be >=1"
+    keep = gt.any(axis=0)
+    S, gt = S[:, keep], gt[:, keep]
     order = S.argsort(axis=0) if sort_kind is None else S.argsort(axis=0, kind=sort_kind)
-    best = order[-K:, :]
-    col = np.tile(np.arange(best.shape[1]), [K, 1])
-    found = gt[best, col]
-    return np.sum(found.sum(axis=0) > 0) / gt.shape[1]
+    recalled = np.take_along_axis(gt, order[-K:, :], axis=0).any(axis=0)
+    return np.count_nonzero(recalled) / gt.shape[1]
 
 
 def recall_from_topk(topk_idx, GThard, K):
@@ -45,53 +52,54 @@ def recall_from_topk(topk_idx, GThard, K):
     return hits / len(cols)
 
 
+def _count_at_least(values, thresholds):
+    """For every threshold, how many of `values` are >= it."""
+    v = np.sort(np.asarray(values).ravel())
+    return v.size - np.searchsorted(v, thresholds, side="left")
+
+
+def _draw_matches(S_in, GThard, best_rows, is_tp, is_fp, path, datatype):
+    """The similarity matrix with the ground truth and, per query, its best match marked as a true or a false
+    positive at the lowest threshold."""
+    import matplotlib.pyplot as plt
+    fig, ax = plt.subplots(figsize=(10, 8))
+    fig.colorbar(ax.imshow(S_in, cmap="viridis", aspect="auto"), ax=ax, label="similarity")
+    rows, cols = np.nonzero(GThard)
+    ax.scatter(cols, rows, s=4, c="white", marker=".", label="ground truth")
+    q = np.arange(S_in.shape[1])
+    ax.scatter(q[is_tp], best_rows[is_tp], s=30, facecolors="none", edgecolors="green", label="best match: true positive")
+    ax.scatter(q[is_fp], best_rows[is_fp], s=30, c="red", marker="x", label="best match: false positive")
+    ax.set(title=f"{datatype}: best match per query", xlabel="query", ylabel="reference place")
+    ax.legend(loc="upper right")
+    fig.tight_layout()
+    fig.savefig(path, dpi=300)
+    plt.close(fig)
+
+
 def createPR(S_in, GThard, outputdir=None, datatype="LENS", GTsoft=None, matching="multi", n_thresh=100):
-    """Precision / recall over n_thresh equally spaced similarity thresholds (behavioural restatement of
-    `createPR`, lens/src/metrics.py:21-139).  'single': every query contributes its best match only (first
-    maximum of its column); 'multi': every matrix entry counts.  Returns the lists P, R starting with the
-    conventional point (P=1, R=0).  With 'single' and an outputdir, the annotated similarity-matrix figure
-    `similarity_matrix_<datatype>.pdf` is written like the reference does."""
-    assert S_in.shape == GThard.shape, "S_in, GThard and GTsoft must have the same shape"
+    """Precision / recall at n_thresh equally spaced similarity thresholds from max(S) down to min(S).
+    'single': every query contributes its best match only (the first maximum of its column); 'multi': every
+    matrix entry counts.  Returns the lists P, R, each starting with the conventional point (P=1, R=0).  With
+    'single' and an outputdir the figure `similarity_matrix_<datatype>.pdf` is written there."""
+    S, gt = _checked(S_in, GThard, GTsoft, "S_in, GThard and GTsoft")
     assert S_in.ndim == 2, "S_in, GThard and GTsoft must be two-dimensional"
     assert matching in ["single", "multi"], "matching should contain one of the following strings: [single, multi]"
     assert n_thresh > 1, "n_thresh must be >1"
-    gt_full = GThard.astype(bool)
-    gt = gt_full
-    S = S_in.copy()
-    if GTsoft is not None:
-        S[GTsoft.astype(bool) & ~gt] = S.min()
     best_rows = None
     if matching == "single":
-        n_positive = np.count_nonzero(gt.any(0))
-        gt = gt[np.argmax(S, axis=0), np.arange(gt.shape[1])]
-        best_rows = np.nanargmax(S, axis=0)
-        S = np.max(S, axis=0)
+        n_positive = np.count_nonzero(gt.any(axis=0))
+        best_rows = np.argmax(S, axis=0)
+        q = np.arange(S.shape[1])
+        gt, S = gt[best_rows, q], S[best_rows, q]
     else:
         n_positive = np.count_nonzero(gt)
-    R, P = [0], [1]
-    hit = None
-    for thr in np.linspace(S.max(), S.min(), n_thresh):
-        hit = S >= thr
-        tp = np.count_nonzero(gt & hit)
-        fp = np.count_nonzero(~gt & hit)
-        P.append(tp / (tp + fp))
-        R.append(tp / n_positive)
+    thresholds = np.linspace(S.max(), S.min(), n_thresh)
+    tp = _count_at_least(S[gt], thresholds)
+    fp = _count_at_least(S[~gt], thresholds)
+    P = [1] + [int(a) / int(a + b) for a, b in zip(tp, fp)]       # the highest threshold always admits max(S)
+    R = [0] + [int(a) / n_positive for a in tp]
     if matching == "single" and outputdir is not None:
-        import matplotlib.pyplot as plt
-        tp_cols, fp_cols = np.where(gt & hit)[0], np.where(~gt & hit)[0]
-        fig, ax = plt.subplots(figsize=(10, 8))
-        im = ax.imshow(S_in, cmap="viridis", aspect="auto")
-        fig.colorbar(im, ax=ax, label="Similarity Score")
-        ax.set_title(f"{datatype} Similarity Matrix with Ground Truth, TP, and FP")
-        gy, gx = np.where(GThard)
-        ax.scatter(gx, gy, facecolors="white", edgecolors="white", marker=".", label="Ground Truth", linewidths=0.5)
-        ax.scatter(tp_cols, best_rows[tp_cols], facecolors="none", edgecolors="green", marker="o",
-                   label="True Positives", linewidths=1.0)
-        ax.scatter(fp_cols, best_rows[fp_cols], marker="x", color="red", label="False Positives", linewidths=1.0)
-        ax.legend(loc="upper right", bbox_to_anchor=(1.0, 1))
-        ax.set_xlabel("Query Index")
-        ax.set_ylabel("Database Index")
-        plt.tight_layout()
-        plt.savefig(os.path.join(outputdir, f"similarity_matrix_{datatype}.pdf"), dpi=300)
-        plt.close()
+        admitted = S >= thresholds[-1]
+        _draw_matches(S_in, GThard, best_rows, gt & admitted, ~gt & admitted,
+                      os.path.join(outputdir, f"similarity_matrix_{datatype}.pdf"), datatype)
     return P, R

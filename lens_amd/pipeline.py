@@ -8,7 +8,7 @@ one batch's tails overlap the next batch's kernels.  Results are identical to th
 batches are independent in `reset` mode, which is the only mode offered here (carried state is sequential in
 the query index by definition, lens/run_model.py:234-242).
 
-Measured on MI355X (scripts/pipeline_experiment.py): 0.365 -> 0.328 ms per 4096-query batch at 1000 places,
+Measured on MI355X (scripts/experiments/pipeline_experiment.py): 0.365 -> 0.328 ms per 4096-query batch at 1000 places,
 no gain at 100 000 places (one kernel dominates there).
 """
 import torch

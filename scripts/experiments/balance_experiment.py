@@ -1,7 +1,7 @@
 """Experiment (development aid): does dealing the queries to SIMDs by predicted cost shorten k_feature_events?
 The frames are permuted on the host so that the kernel's natural slot order realises the deal."""
 import os, sys, time, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import pretrained_example
 from lens_amd.engine import LensEngine, centre_pixel_index

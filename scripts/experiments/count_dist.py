@@ -1,5 +1,5 @@
 import sys, os, torch, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import pretrained_example, load_config
 from lens_amd.engine import LensEngine
 from lens_amd.synthetic import synthetic_frames, synthetic_database

@@ -1,6 +1,6 @@
 """How much do HIP event records between the kernels of a step cost? (development aid)"""
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import pretrained_example
 from lens_amd.engine import LensEngine, seqmatch_topk

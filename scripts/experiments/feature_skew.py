@@ -1,6 +1,6 @@
 """How skewed is feature activity? (development aid) fraction of events covered by the top-k features."""
 import sys, os, torch, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import pretrained_example, load_config
 from lens_amd.engine import LensEngine

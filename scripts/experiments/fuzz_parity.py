@@ -2,7 +2,7 @@
 GPU path vs the CPU oracle, bit-exact.  Usage: fuzz_parity.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from lens_amd.engine import LensEngine, seqmatch, seqmatch_topk
 from oracle import oracle as O

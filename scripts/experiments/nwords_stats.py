@@ -1,6 +1,6 @@
 """Distribution of the spike-stream lengths (development aid): load balance of the output kernel's waves."""
 import sys, os, torch, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import pretrained_example
 from lens_amd.engine import LensEngine

@@ -1,6 +1,6 @@
 """Batch pipelining: throughput vs number of streams (development aid; 2-3 streams are equal, 4 collapses)."""
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import pretrained_example
 from lens_amd.pipeline import BatchPipeline

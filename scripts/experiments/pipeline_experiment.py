@@ -1,7 +1,7 @@
 """Experiment (development aid): alternate batches over two HIP streams with separate workspaces, so that one batch's
 kernel tails overlap the next batch's kernels.  Prints sequential vs pipelined batch rate."""
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import pretrained_example
 from lens_amd.engine import LensEngine, seqmatch_topk

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counters of the three hot kernels on the quick_bench workload (development aid). Usage: scripts/pmc_quick.sh <tag> [quick_bench args]
+# PMC counters of the three hot kernels on the quick_bench workload (development aid). Usage: scripts/experiments/pmc_quick.sh <tag> [quick_bench args]
 set -u
 TAG=${1:-x}; shift || true
 export TMPDIR=/tmp

@@ -82,6 +82,44 @@ KERNEL(k_iafs, REP8(IAF_S))
 #define IAF_P "v_pk_add_f32 %[accp], %[accp], %[wp]\n v_max_f32 %4, %0, %1\n v_cmp_le_f32 vcc, 1.0, %4\n s_cbranch_vccz 1f\n 1:\n v_pk_fma_f32 %[accp], %[accp], %[half], %[half] clamp\n v_pk_fma_f32 %[accp], %[accp], %[two], %[mone]\n v_mov_b64 %[wp], 0\n"
 KERNEL(k_iafp, REP8(IAF_P))
 
+// The whole instruction mix of k_output_counts per 16-event chunk, with nothing to wait for but the LDS reads:
+// 16 x (address add with an SGPR source + ds_read_b64), one lgkmcnt(0), then 16 single-spike events (two VGPR adds,
+// compare, branch) of which every fourth ends a time step: taken branch to an out-of-line block (membrane adds,
+// threshold test, taken branch over the spike path, 4-FMA clip, zeroing, the next event's two adds) and back.
+// Its time per chunk is the issue floor of that mix; compare with the kernel's time per chunk.
+#define MIX_RD "v_add_u32 %4, s20, %7\n ds_read_b64 %5, %4\n"
+#define MIX_EV "v_add_f32 %0, %0, %2\n s_cmp_gt_i32 %6, -1\n v_add_f32 %1, %1, %3\n s_cbranch_scc0 90f\n"
+#define MIX_LAST(n) "v_add_f32 %0, %0, %2\n s_cmp_gt_i32 %6, -1\n v_add_f32 %1, %1, %3\n s_cbranch_scc1 1" #n "f\n 2" #n ":\n"
+#define MIX_STEP(n) "1" #n ":\n v_add_f32 %2, %2, %0\n v_add_f32 %3, %3, %1\n v_max_f32 %4, %2, %3\n v_cmp_le_f32 vcc, 0x7f000000, %4\n s_cbranch_vccz 3" #n "f\n" \
+                    " v_max_f32 %4, 0, %2\n v_floor_f32 %4, %4\n v_sub_f32 %2, %2, %4\n 3" #n ":\n" \
+                    " v_fma_f32 %2, %2, 0.5, 0.5 clamp\n v_fma_f32 %3, %3, 0.5, 0.5 clamp\n v_fma_f32 %2, %2, 2.0, -1.0\n v_fma_f32 %3, %3, 2.0, -1.0\n" \
+                    " v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc1 2" #n "b\n"
+#define MIX_CHUNK "s_lshl_b32 s20, %6, 9\n" MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD \
+                  "s_waitcnt lgkmcnt(0)\n" \
+                  MIX_EV MIX_EV MIX_EV MIX_LAST(1) MIX_EV MIX_EV MIX_EV MIX_LAST(2) MIX_EV MIX_EV MIX_EV MIX_LAST(3) MIX_EV MIX_EV MIX_EV MIX_LAST(4) \
+                  "s_branch 90f\n" MIX_STEP(1) MIX_STEP(2) MIX_STEP(3) MIX_STEP(4) "90:\n"
+KERNEL(k_mix16, MIX_CHUNK)
+// the same mix with the weight reads software-pipelined: wait for the reads issued one chunk earlier, issue the next
+// chunk's reads, then integrate (what a planar stream layout -- offsets of chunk c+1 available while chunk c is
+// integrated -- would allow)
+#define MIX_RD16 MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD MIX_RD
+#define MIX_EVS MIX_EV MIX_EV MIX_EV MIX_LAST(1) MIX_EV MIX_EV MIX_EV MIX_LAST(2) MIX_EV MIX_EV MIX_EV MIX_LAST(3) MIX_EV MIX_EV MIX_EV MIX_LAST(4)
+#define MIX_STEPS "s_branch 90f\n" MIX_STEP(1) MIX_STEP(2) MIX_STEP(3) MIX_STEP(4) "90:\n"
+KERNEL(k_mix16pre, "s_lshl_b32 s20, %6, 9\n s_waitcnt lgkmcnt(0)\n" MIX_RD16 MIX_EVS MIX_STEPS)
+// ... and without any LDS read (address adds kept): the share of the reads' issue and wait
+#define MIX_AD "v_add_u32 %4, s20, %7\n"
+KERNEL(k_mix16nolds, "s_lshl_b32 s20, %6, 9\n" MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_AD MIX_EVS MIX_STEPS)
+// ... and with the event branches never taken and no step blocks (16 plain events): the share of the time steps
+#define MIX_EV16 MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV MIX_EV
+KERNEL(k_mix16nostep, "s_lshl_b32 s20, %6, 9\n" MIX_RD16 "s_waitcnt lgkmcnt(0)\n" MIX_EV16 "90:\n")
+// ... the step blocks inline (no taken branch into and out of them; the branch over the spike path stays)
+#define MIX_STEPIN(n) "v_add_f32 %0, %0, %2\n s_cmp_gt_i32 %6, -1\n v_add_f32 %1, %1, %3\n s_cbranch_scc0 2" #n "f\n" \
+                    " v_add_f32 %2, %2, %0\n v_add_f32 %3, %3, %1\n v_max_f32 %4, %2, %3\n v_cmp_le_f32 vcc, 0x7f000000, %4\n s_cbranch_vccz 3" #n "f\n" \
+                    " v_max_f32 %4, 0, %2\n v_floor_f32 %4, %4\n v_sub_f32 %2, %2, %4\n 3" #n ":\n" \
+                    " v_fma_f32 %2, %2, 0.5, 0.5 clamp\n v_fma_f32 %3, %3, 0.5, 0.5 clamp\n v_fma_f32 %2, %2, 2.0, -1.0\n v_fma_f32 %3, %3, 2.0, -1.0\n" \
+                    " v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n 2" #n ":\n"
+KERNEL(k_mix16inl, "s_lshl_b32 s20, %6, 9\n s_waitcnt lgkmcnt(0)\n" MIX_RD16 MIX_EV MIX_EV MIX_EV MIX_STEPIN(1) MIX_EV MIX_EV MIX_EV MIX_STEPIN(2) MIX_EV MIX_EV MIX_EV MIX_STEPIN(3) MIX_EV MIX_EV MIX_EV MIX_STEPIN(4) "90:\n")
+
 template <typename K>
 void run(const char *name, K kern) {
     unsigned long long *d; hipMalloc(&d, 512 * 16 * 8);
@@ -110,6 +148,8 @@ int main(int argc, char **argv) {
     RUN("cur", k_cur) RUN("dpp", k_dpp) RUN("dpp_nolds", k_dppnl) RUN("valu3", k_v3) RUN("valu3+lds", k_v3l)
     RUN("valu3+s", k_v3s) RUN("valu3+sb", k_v3sb) RUN("ppl4", k_p4)
     RUN("ev_s2", k_s2) RUN("ev_pk", k_pk) RUN("iaf_s", k_iafs) RUN("iaf_p", k_iafp)
+    RUN("mix16", k_mix16)   // "events" in its printout are whole 16-event chunks / 8
+    RUN("mix16pre", k_mix16pre) RUN("mix16nolds", k_mix16nolds) RUN("mix16nostep", k_mix16nostep) RUN("mix16inl", k_mix16inl)
     RUN("add2", k_a2) RUN("add2+nt", k_nt) RUN("add2+tk", k_tk) RUN("add2+tk2", k_tk2) RUN("add2+call", k_call)
     return 0;
 }

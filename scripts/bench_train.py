@@ -15,8 +15,8 @@ a = ap.parse_args()
 torch.manual_seed(0); np.random.seed(0)
 dev = torch.device("cuda")
 S, T = a.samples, a.steps
-x = (torch.rand(S, 100) * (torch.rand(S, 100) < 0.5)).float()
-for name, n_in, n_out, spk in (("feature", 100, 200, False), ("output", 200, a.places, True)):
+for name, n_in, n_out, spk in (("feature", 100, 200, False), ("output", 200, a.places, True),
+                               ("feature", 400, 800, False), ("output", 800, 10000, True)):      # --dims 20: rows over 4 / 8 lanes
     L = SNNLayer(dims=[n_in, n_out], thr_range=[0, 0.5], fire_rate=[0.4, 0.6], ip_rate=0.02, stdp_rate=0.01,
                  p=[0.35, 0.75] if not spk else [1.0, 1.0], spk_force=spk)
     ld = E.train_in_pad(n_in)

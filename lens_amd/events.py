@@ -4,8 +4,9 @@ The reference turns events into frames in one place, `create_images` of lens/col
 `timebin` milliseconds the events received since the last call become one `roi x roi` frame
 (`frame[e.y-1, e.x-1] += 1`, stored as uint8, i.e. counts wrap modulo 256), written as
 `frame_%05d.png`; a window without events writes nothing and does not advance the frame number.
-Recorded streams come as text, one `t x y p` line per event after a header line with the sensor size
-(the format lens/tools/dvstools.py:282-290 reads); this module windows such a stream the same way and
+Recorded streams come as text, one `t x y p` line per event after a header line with the sensor size,
+usually inside a zip archive (the format lens/tools/dvstools.py:270-290 reads); this module reads that form,
+the bare text file and a parquet table with the same columns, windows the stream the same way and
 accumulates all windows with one `lens_accumulate_events` launch.  There is no CPU accumulation path.
 """
 import os
@@ -16,8 +17,40 @@ import torch
 from .engine import accumulate_events
 
 
+def load_events(path, skip_header=True):
+    """A recorded event stream from disk: float64 t, int64 x, y, p.  By file type:
+    `.zip`  -- the archive form lens/tools/dvstools.py:270-283 reads: the member `<archive stem>.txt` (or the
+               only `.txt` member), first line = sensor size, then `t x y p` per line;
+    `.parquet` -- columns t, x, y and optionally p (pyarrow);
+    anything else -- the plain text form, see load_event_text."""
+    low = path.lower()
+    if low.endswith(".zip"):
+        import io
+        import zipfile
+        with zipfile.ZipFile(path) as z:
+            names = [n for n in z.namelist() if n.lower().endswith(".txt")]
+            want = os.path.splitext(os.path.basename(path))[0] + ".txt"
+            member = want if want in names else (names[0] if len(names) == 1 else None)
+            if member is None:
+                raise ValueError(f"{path}: expected the member {want} or exactly one .txt member, found {names}")
+            with z.open(member) as fh:
+                return load_event_text(io.TextIOWrapper(fh, encoding="ascii"), skip_header=skip_header)
+    if low.endswith(".parquet"):
+        import pyarrow.parquet as pq
+        tab = pq.read_table(path)
+        missing = [c for c in ("t", "x", "y") if c not in tab.column_names]
+        if missing:
+            raise ValueError(f"{path}: missing column(s) {missing} (need t, x, y and optionally p)")
+        col = lambda n, dt: tab.column(n).to_numpy().astype(dt)
+        x = col("x", np.int64)
+        return col("t", np.float64), x, col("y", np.int64), (col("p", np.int64) if "p" in tab.column_names
+                                                           else np.zeros_like(x))
+    return load_event_text(path, skip_header=skip_header)
+
+
 def load_event_text(path, skip_header=True):
-    """`t x y p` per line (whitespace separated, t in the file's own unit).  Returns float64 t, int64 x, y, p."""
+    """`t x y p` per line (whitespace separated, t in the file's own unit); `path` is a file name or an open
+    text file.  Returns float64 t, int64 x, y, p."""
     rows = np.loadtxt(path, dtype=np.float64, skiprows=1 if skip_header else 0, ndmin=2)
     if rows.shape[1] < 3:
         raise ValueError(f"{path}: expected at least 3 columns (t x y [p]), found {rows.shape[1]}")
@@ -86,7 +119,8 @@ def save_frames(frames, folder, start_index=0):
 
 def main(argv=None):
     import argparse
-    ap = argparse.ArgumentParser(description="event text (t x y p) -> frame_%05d.png count frames, accumulated on the GPU")
+    ap = argparse.ArgumentParser(description="event recording (t x y p as text, text inside a .zip, or .parquet) -> "
+                                             "frame_%05d.png count frames, accumulated on the GPU")
     ap.add_argument("events")
     ap.add_argument("out_dir")
     ap.add_argument("--timebin", type=float, default=1000.0, help="window length in ms (LENS default 1000)")
@@ -95,7 +129,7 @@ def main(argv=None):
     ap.add_argument("--zero_based", action="store_true", help="coordinates start at 0 (recorded text files) instead of 1")
     ap.add_argument("--no_header", action="store_true")
     a = ap.parse_args(argv)
-    t, x, y, _ = load_event_text(a.events, skip_header=not a.no_header)
+    t, x, y, _ = load_events(a.events, skip_header=not a.no_header)
     frames, win = frames_from_events(t, x, y, a.timebin, a.roi_dim, a.t_unit, one_based=not a.zero_based)
     paths = save_frames(frames, a.out_dir)
     print(f"{len(paths)} frames ({int(win[-1]) + 1 if len(win) else 0} windows) -> {a.out_dir}")

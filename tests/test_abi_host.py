@@ -267,6 +267,23 @@ def test_event_windows_skip_empty_windows(tmp_path):
     p.write_text("128 128\n100 3 4 1\n250.5 7 8 0\n")
     tt, x, y, pol = load_event_text(str(p))
     assert tt.tolist() == [100.0, 250.5] and x.tolist() == [3, 7] and y.tolist() == [4, 8] and pol.tolist() == [1, 0]
+    # the same recording inside a zip archive (member <stem>.txt, lens/tools/dvstools.py:270-283) and as parquet
+    import zipfile
+    from lens_amd.events import load_events
+    z = tmp_path / "rec.zip"
+    with zipfile.ZipFile(z, "w") as zf:
+        zf.writestr("rec.txt", p.read_text())
+        zf.writestr("notes.md", "x")
+    for got in (load_events(str(z)), load_events(str(p))):
+        assert [a.tolist() for a in got] == [[100.0, 250.5], [3, 7], [4, 8], [1, 0]]
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    pq.write_table(pa.table({"t": [100.0, 250.5], "x": [3, 7], "y": [4, 8]}), tmp_path / "rec.parquet")
+    tt, x, y, pol = load_events(str(tmp_path / "rec.parquet"))
+    assert tt.tolist() == [100.0, 250.5] and x.tolist() == [3, 7] and y.tolist() == [4, 8] and pol.tolist() == [0, 0]
+    with pytest.raises(ValueError):
+        pq.write_table(pa.table({"t": [1.0], "x": [3]}), tmp_path / "bad.parquet")
+        load_events(str(tmp_path / "bad.parquet"))
 
 
 def test_training_pad_covers_wide_layers_and_short_csv_annealing():

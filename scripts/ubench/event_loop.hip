@@ -31,6 +31,27 @@ __global__ void __launch_bounds__(1024) name(unsigned long long *out, float seed
     if (a0 + a1 + a2 + a3 + (float)w + (float)s0 + (float)addr + accp.x + accp.y + wp.x == 12345.678f) out[0] = 0; \
 }
 
+#define KERNEL4(name, body)                                                                        \
+__global__ void __launch_bounds__(1024) name(unsigned long long *out, float seed, unsigned us) {  \
+    __shared__ float tile[8192];                                                                  \
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) tile[i] = seed + i;                      \
+    __syncthreads();                                                                              \
+    float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3;                                 \
+    unsigned addr = 0; double w = 0; unsigned s0 = us;                                            \
+    unsigned lane8 = (threadIdx.x & 63) * 8; float cntv = seed * (threadIdx.x & 15);              \
+    unsigned offs = 512 + 0 * threadIdx.x; float smul = seed;                                  \
+    typedef float v2f __attribute__((ext_vector_type(2)));                                        \
+    typedef float v4f __attribute__((ext_vector_type(4))); v4f accp4 = {seed, seed, seed, seed}; v2f accp = {seed, seed}, wp = {seed * 0.001f, seed * 0.002f}, half = {0.5f, 0.5f}, two = {2.0f, 2.0f}, mone = {-1.0f, -1.0f}; \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+    for (int i = 0; i < ITER; ++i) {                                                              \
+        asm volatile(body : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(addr), "+v"(w), "+s"(s0) \
+                     : "v"(lane8), "v"(cntv), "s"(smul), "v"(offs), [accp] "v"(accp), [accp4] "v"(accp4), [wp] "v"(wp), [half] "v"(half), [two] "v"(two), [mone] "v"(mone) : "scc", "vcc", "s20", "s21"); \
+    }                                                                                             \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+    if (threadIdx.x % 64 == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;       \
+    if (a0 + a1 + a2 + a3 + (float)w + (float)s0 + (float)addr + accp.x + accp.y + wp.x == 12345.678f) out[0] = 0; \
+}
+
 // current kernel's event: SGPR-sourced offset and count
 #define EV_CUR "v_add_u32 %4, %6, %7\n ds_read_b64 %5, %4\n s_waitcnt lgkmcnt(3)\n v_fma_f32 %0, |%9|, %2, %0\n s_cmp_gt_i32 %6, -1\n v_fma_f32 %1, |%9|, %3, %1\n s_cbranch_scc0 1f\n 1:\n"
 KERNEL(k_cur, REP8(EV_CUR))
@@ -120,6 +141,23 @@ KERNEL(k_mix16nostep, "s_lshl_b32 s20, %6, 9\n" MIX_RD16 "s_waitcnt lgkmcnt(0)\n
                     " v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n 2" #n ":\n"
 KERNEL(k_mix16inl, "s_lshl_b32 s20, %6, 9\n s_waitcnt lgkmcnt(0)\n" MIX_RD16 MIX_EV MIX_EV MIX_EV MIX_STEPIN(1) MIX_EV MIX_EV MIX_EV MIX_STEPIN(2) MIX_EV MIX_EV MIX_EV MIX_STEPIN(3) MIX_EV MIX_EV MIX_EV MIX_STEPIN(4) "90:\n")
 
+// what a hand-written loop could remove: (z) the two zeroings per step and the two adds of the event that follows a
+// step (its weights ARE the new sum); (v) the address add from a VGPR-held offset (full rate) with the offsets of a
+// chunk fetched by four broadcast ds_read_b128; (zv) both
+#define MIX_EV0 "s_cmp_gt_i32 %6, -1\n s_cbranch_scc0 90f\n"
+#define MIX_STEPZ(n) "1" #n ":\n v_add_f32 %2, %2, %0\n v_add_f32 %3, %3, %1\n v_max_f32 %4, %2, %3\n v_cmp_le_f32 vcc, 0x7f000000, %4\n s_cbranch_vccz 3" #n "f\n" \
+                    " v_max_f32 %4, 0, %2\n v_floor_f32 %4, %4\n v_sub_f32 %2, %2, %4\n 3" #n ":\n" \
+                    " v_fma_f32 %2, %2, 0.5, 0.5 clamp\n v_fma_f32 %3, %3, 0.5, 0.5 clamp\n v_fma_f32 %2, %2, 2.0, -1.0\n v_fma_f32 %3, %3, 2.0, -1.0\n" \
+                    " s_cmp_gt_i32 %6, -1\n s_cbranch_scc1 2" #n "b\n"
+#define MIX_EVSZ MIX_EV MIX_EV MIX_EV MIX_LAST(1) MIX_EV0 MIX_EV MIX_EV MIX_LAST(2) MIX_EV0 MIX_EV MIX_EV MIX_LAST(3) MIX_EV0 MIX_EV MIX_EV MIX_LAST(4)
+#define MIX_STEPSZ "s_branch 90f\n" MIX_STEPZ(1) MIX_STEPZ(2) MIX_STEPZ(3) MIX_STEPZ(4) "90:\n"
+KERNEL(k_mix16z, "s_lshl_b32 s20, %6, 9\n" MIX_RD16 "s_waitcnt lgkmcnt(0)\n" MIX_EVSZ MIX_STEPSZ)
+#define MIX_RDV "v_add_u32 %4, %10, %7\n ds_read_b64 %5, %4\n"
+#define MIX_RDV16 MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV MIX_RDV
+#define MIX_OFFS "ds_read_b128 %[accp4], %10\n ds_read_b128 %[accp4], %10 offset:16\n ds_read_b128 %[accp4], %10 offset:32\n ds_read_b128 %[accp4], %10 offset:48\n"
+KERNEL4(k_mix16v, MIX_RDV16 MIX_OFFS "s_waitcnt lgkmcnt(0)\n" MIX_EVS MIX_STEPS)
+KERNEL4(k_mix16zv, MIX_RDV16 MIX_OFFS "s_waitcnt lgkmcnt(0)\n" MIX_EVSZ MIX_STEPSZ)
+
 template <typename K>
 void run(const char *name, K kern) {
     unsigned long long *d; hipMalloc(&d, 512 * 16 * 8);
@@ -149,6 +187,7 @@ int main(int argc, char **argv) {
     RUN("valu3+s", k_v3s) RUN("valu3+sb", k_v3sb) RUN("ppl4", k_p4)
     RUN("ev_s2", k_s2) RUN("ev_pk", k_pk) RUN("iaf_s", k_iafs) RUN("iaf_p", k_iafp)
     RUN("mix16", k_mix16)   // "events" in its printout are whole 16-event chunks / 8
+    RUN("mix16z", k_mix16z) RUN("mix16v", k_mix16v) RUN("mix16zv", k_mix16zv)
     RUN("mix16pre", k_mix16pre) RUN("mix16nolds", k_mix16nolds) RUN("mix16nostep", k_mix16nostep) RUN("mix16inl", k_mix16inl)
     RUN("add2", k_a2) RUN("add2+nt", k_nt) RUN("add2+tk", k_tk) RUN("add2+tk2", k_tk2) RUN("add2+call", k_call)
     return 0;

@@ -216,6 +216,29 @@ def secondary_config2(w1, w2p, frames, dev, steps):
     return res
 
 
+def real_density(w1, w2, dev, Q, steps=3):
+    """The timed workload's shape on REAL event frames: the bundled example's 100 query frames (80x80, ~8 feature
+    spikes per step instead of the synthetic generator's 2.6) tiled to Q queries against the same database."""
+    from lens_amd.dataset import CustomImageDataset
+    from lens_amd.engine import LensEngine, seqmatch_topk
+    base = os.path.join(ROOT, "lens", "dataset")
+    ds = CustomImageDataset(os.path.join(base, "example-query.csv"), os.path.join(base, "example", "davis128", "example-query"))
+    fr = ds.frames()
+    frames = fr.repeat((Q + len(fr) - 1) // len(fr), 1, 1)[:Q].contiguous().to(dev)
+    eng = LensEngine(w1, w2, fr.shape[1], DIMS, T_STEPS, device=dev, max_batch=Q)
+
+    def step(_e=None):
+        eng.feature_events(frames, carry=False)
+        seqmatch_topk(eng.output_counts(Q, carry=False), SEQ_L, TOPK)
+
+    step()
+    dt = time_steps(step, steps)
+    return {"value": Q * steps / dt, "unit": "query event-frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "feature_spike_words_per_query": float(eng.nwords[:Q].float().mean().item()),
+            "workload": f"bundled example query frames ({fr.shape[1]}x{fr.shape[2]}, recorded events) tiled to {Q} "
+                        f"queries, {w2.shape[0]}-place DB, state reset per query"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -400,6 +423,7 @@ def main():
             line["other_kernels"] = other_kernel_rooflines(frames_cpu, dev, avg_ms[2], topk_bytes)
             if a.places != 1000:
                 line["other_configs"] = secondary_config2(w1, w2p, frames, dev, min(a.steps, 20))
+            line.setdefault("other_configs", {})["real_density"] = real_density(w1, w2, dev, Q)
             if pipe is None:
                 from lens_amd.pipeline import BatchPipeline
                 p2 = BatchPipeline(w1, w2, ROI, DIMS, T_STEPS, device=dev, max_batch=Q)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 6
+#define LENS_AMD_ABI_VERSION 7
 
 /* Size of the library-owned device array behind lens_forward_counts_static (held once per GPU in use). */
 #define LENS_STATIC_SCRATCH_BYTES (64u << 20)
@@ -83,10 +83,11 @@ int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_co
 /* Words of `events` a query needs in the worst case: 2 * T * max(F, 1) rounded up to whole 32-word chunks. */
 size_t lens_event_capacity_words(int T, int F);
 
-/* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F) can consume
- * its streams: the byte stride of one W2^T row in the output kernel's LDS tile (1 if the tile does
- * not fit in LDS and the weights are read through L2). */
-int lens_event_scale(int F);
+/* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F and P) can consume
+ * its streams: the byte stride of one W2^T row in the output kernel's LDS tile (1 if no tile fits in
+ * LDS and the weights are read through L2).  The tile is 64, 128, 192 or 256 places wide, whichever
+ * fits F and costs least for P, so the scale depends on both. */
+int lens_event_scale(int F, int P);
 
 /*
  * Frames -> feature-layer spike streams.  Replaces, for a batch of Q queries,

@@ -122,7 +122,7 @@ class LensEngine:
         # the spike-stream workspace is sized for the worst case (every feature spikes every step):
         # keep it below ~4 GB by limiting the queries processed per launch
         self.max_batch = max(1, min(self.max_batch, (4 << 30) // (4 * self.cap)))
-        self.ev_scale = int(_lib.lib().lens_event_scale(self.F))
+        self.ev_scale = int(_lib.lib().lens_event_scale(self.F, self.P))
         self.n_streams = 1
         self.reset_state()
         self._ws_q = 0

@@ -37,19 +37,19 @@ __global__ void __launch_bounds__(1024) name(unsigned long long *out, float seed
     for (int i = threadIdx.x; i < 8192; i += blockDim.x) tile[i] = seed + i;                      \
     __syncthreads();                                                                              \
     float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3;                                 \
-    unsigned addr = 0; double w = 0; unsigned s0 = us;                                            \
+    unsigned addr = 0; double w = 0; unsigned s0 = us; unsigned b2 = 0; float w3 = seed * 0.003f, c3 = seed, v3 = seed * 0.1f;                                            \
     unsigned lane8 = (threadIdx.x & 63) * 8; float cntv = seed * (threadIdx.x & 15);              \
     unsigned offs = 512 + 0 * threadIdx.x; float smul = seed;                                  \
     typedef float v2f __attribute__((ext_vector_type(2)));                                        \
-    typedef float v4f __attribute__((ext_vector_type(4))); v4f accp4 = {seed, seed, seed, seed}; v2f accp = {seed, seed}, wp = {seed * 0.001f, seed * 0.002f}, half = {0.5f, 0.5f}, two = {2.0f, 2.0f}, mone = {-1.0f, -1.0f}; \
+    typedef float v3f __attribute__((ext_vector_type(3))); v3f w96 = {seed, seed, seed}; unsigned lane12 = (threadIdx.x & 63) * 12; unsigned lane4 = (threadIdx.x & 63) * 4; typedef float v4f __attribute__((ext_vector_type(4))); v4f accp4 = {seed, seed, seed, seed}; v2f accp = {seed, seed}, wp = {seed * 0.001f, seed * 0.002f}, half = {0.5f, 0.5f}, two = {2.0f, 2.0f}, mone = {-1.0f, -1.0f}; \
     unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
     for (int i = 0; i < ITER; ++i) {                                                              \
-        asm volatile(body : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(addr), "+v"(w), "+s"(s0) \
-                     : "v"(lane8), "v"(cntv), "s"(smul), "v"(offs), [accp] "v"(accp), [accp4] "v"(accp4), [wp] "v"(wp), [half] "v"(half), [two] "v"(two), [mone] "v"(mone) : "scc", "vcc", "s20", "s21"); \
+        asm volatile(body : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(addr), "+v"(w), "+s"(s0), [b2] "+v"(b2), [w3] "+v"(w3), [c3] "+v"(c3), [v3] "+v"(v3), [w96] "+v"(w96) \
+                     : "v"(lane8), "v"(cntv), "s"(smul), "v"(offs), [accp] "v"(accp), [accp4] "v"(accp4), [lane12] "v"(lane12), [lane4] "v"(lane4), [wp] "v"(wp), [half] "v"(half), [two] "v"(two), [mone] "v"(mone) : "scc", "vcc", "s20", "s21"); \
     }                                                                                             \
     unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
     if (threadIdx.x % 64 == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;       \
-    if (a0 + a1 + a2 + a3 + (float)w + (float)s0 + (float)addr + accp.x + accp.y + wp.x == 12345.678f) out[0] = 0; \
+    if (a0 + a1 + a2 + a3 + (float)w + (float)s0 + (float)addr + (float)b2 + w3 + c3 + v3 + w96.x + w96.z + accp.x + accp.y + wp.x == 12345.678f) out[0] = 0; \
 }
 
 // current kernel's event: SGPR-sourced offset and count
@@ -158,6 +158,33 @@ KERNEL(k_mix16z, "s_lshl_b32 s20, %6, 9\n" MIX_RD16 "s_waitcnt lgkmcnt(0)\n" MIX
 KERNEL4(k_mix16v, MIX_RDV16 MIX_OFFS "s_waitcnt lgkmcnt(0)\n" MIX_EVS MIX_STEPS)
 KERNEL4(k_mix16zv, MIX_RDV16 MIX_OFFS "s_waitcnt lgkmcnt(0)\n" MIX_EVSZ MIX_STEPSZ)
 
+// three places per lane (a 150 KB tile at F = 200): second address VGPR-only, ds_read_b64 + ds_read_b32, 3 adds per
+// event, 3-wide step blocks.  Time per chunk covers 192 places instead of 128.
+#define P3_RD "v_add_u32 %4, s20, %7\n v_add_u32 %[b2], %4, %10\n ds_read_b64 %5, %4\n ds_read_b32 %[w3], %[b2]\n"
+#define P3_RD16 P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD P3_RD
+#define P3_EV "v_add_f32 %0, %0, %2\n s_cmp_gt_i32 %6, -1\n v_add_f32 %1, %1, %3\n v_add_f32 %[c3], %[c3], %[w3]\n s_cbranch_scc0 90f\n"
+#define P3_LAST(n) "v_add_f32 %0, %0, %2\n s_cmp_gt_i32 %6, -1\n v_add_f32 %1, %1, %3\n v_add_f32 %[c3], %[c3], %[w3]\n s_cbranch_scc1 1" #n "f\n 2" #n ":\n"
+#define P3_STEP(n) "1" #n ":\n v_add_f32 %2, %2, %0\n v_add_f32 %3, %3, %1\n v_add_f32 %[v3], %[v3], %[c3]\n v_max3_f32 %4, %2, %3, %[v3]\n v_cmp_le_f32 vcc, 0x7f000000, %4\n s_cbranch_vccnz 3" #n "f\n" \
+                    " v_fma_f32 %2, %2, 0.5, 0.5 clamp\n v_fma_f32 %3, %3, 0.5, 0.5 clamp\n v_fma_f32 %[v3], %[v3], 0.5, 0.5 clamp\n v_fma_f32 %2, %2, 2.0, -1.0\n v_fma_f32 %3, %3, 2.0, -1.0\n v_fma_f32 %[v3], %[v3], 2.0, -1.0\n" \
+                    " v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n v_mov_b32 %[c3], 0\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc1 2" #n "b\n 3" #n ":\n"
+#define P3_EVS P3_EV P3_EV P3_EV P3_LAST(1) P3_EV P3_EV P3_EV P3_LAST(2) P3_EV P3_EV P3_EV P3_LAST(3) P3_EV P3_EV P3_EV P3_LAST(4)
+KERNEL4(k_mix16p3, "s_lshl_b32 s20, %6, 9\n" P3_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+// the two-places mix with the spike-path branch not taken (as the shipped kernel lays it out), for comparison
+#define MIX_STEPN(n) "1" #n ":\n v_add_f32 %2, %2, %0\n v_add_f32 %3, %3, %1\n v_max_f32 %4, %2, %3\n v_cmp_le_f32 vcc, 0x7f000000, %4\n s_cbranch_vccnz 3" #n "f\n" \
+                    " v_fma_f32 %2, %2, 0.5, 0.5 clamp\n v_fma_f32 %3, %3, 0.5, 0.5 clamp\n v_fma_f32 %2, %2, 2.0, -1.0\n v_fma_f32 %3, %3, 2.0, -1.0\n" \
+                    " v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n s_cmp_gt_i32 %6, -1\n s_cbranch_scc1 2" #n "b\n 3" #n ":\n"
+KERNEL4(k_mix16n, "s_lshl_b32 s20, %6, 9\n" MIX_RD16 "s_waitcnt lgkmcnt(0)\n" MIX_EVS "s_branch 90f\n" MIX_STEPN(1) MIX_STEPN(2) MIX_STEPN(3) MIX_STEPN(4) "90:\n")
+
+// three places per lane through one 12-byte read per event (lane stride 12 bytes, 4-byte aligned)
+#define P3B_RD "v_add_u32 %4, s20, %[lane12]\n ds_read_b96 %[w96], %4\n"
+#define P3B_RD16 P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD P3B_RD
+KERNEL4(k_mix16p3b, "s_lshl_b32 s20, %6, 9\n" P3B_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+
+// three places per lane at lane stride 4 bytes: places l, 64+l, 128+l of a 768-byte row; one address, two reads
+#define P3C_RD "v_add_u32 %4, s20, %[lane4]\n ds_read2_b32 %5, %4 offset1:64\n ds_read_b32 %[w3], %4 offset:512\n"
+#define P3C_RD16 P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD P3C_RD
+KERNEL4(k_mix16p3c, "s_lshl_b32 s20, %6, 9\n" P3C_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+
 template <typename K>
 void run(const char *name, K kern) {
     unsigned long long *d; hipMalloc(&d, 512 * 16 * 8);
@@ -187,6 +214,7 @@ int main(int argc, char **argv) {
     RUN("valu3+s", k_v3s) RUN("valu3+sb", k_v3sb) RUN("ppl4", k_p4)
     RUN("ev_s2", k_s2) RUN("ev_pk", k_pk) RUN("iaf_s", k_iafs) RUN("iaf_p", k_iafp)
     RUN("mix16", k_mix16)   // "events" in its printout are whole 16-event chunks / 8
+    RUN("mix16p3", k_mix16p3) RUN("mix16p3b", k_mix16p3b) RUN("mix16p3c", k_mix16p3c) RUN("mix16n", k_mix16n)
     RUN("mix16z", k_mix16z) RUN("mix16v", k_mix16v) RUN("mix16zv", k_mix16zv)
     RUN("mix16pre", k_mix16pre) RUN("mix16nolds", k_mix16nolds) RUN("mix16nostep", k_mix16nostep) RUN("mix16inl", k_mix16inl)
     RUN("add2", k_a2) RUN("add2+nt", k_nt) RUN("add2+tk", k_tk) RUN("add2+tk2", k_tk2) RUN("add2+call", k_call)

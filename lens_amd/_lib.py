@@ -12,7 +12,8 @@ ROOT = os.path.dirname(_PKG)
 # LENS_AMD_SO selects another in-tree build of the same sources (kernel experiments); the default is the product.
 SO_PATH = os.environ.get("LENS_AMD_SO") or os.path.join(_PKG, "liblens_amd.so")
 SRC = os.path.join(_PKG, "csrc", "lens_kernels.hip")
-INCLUDES = [os.path.join(_PKG, "csrc", "feature_loop_n2f4.inc")]     # textually included by SRC
+INCLUDES = [os.path.join(_PKG, "csrc", n)                            # textually included by SRC
+            for n in ("feature_loop_n2f4.inc", "output_loop_p2.inc", "output_loop_p3.inc")]
 HEADER = os.path.join(ROOT, "include", "lens_amd.h")
 
 # -ffp-contract=off: the only fused operations are the explicit fmaf calls (numerics contract).

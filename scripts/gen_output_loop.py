@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Generates lens_amd/csrc/output_loop_p{2,3}.inc: gfx950 assembly of k_output_counts' chunk loop for one query
+against an LDS weight tile of 128 (two places per lane) or 192 places (three per lane).  The generated files
+are committed; rerun this script after editing.
+
+Why assembly: the loop runs at the issue rate of its instruction mix (4 waves per SIMD next to the 100-150 KB
+tile), and the shape that needs the fewest instructions and taken branches cannot be written in C++ -- the
+compiler's control-flow structurizer turns it into flag bookkeeping.  The shape is two chains of code per chunk:
+  A<i>  accumulates event i (acc += count * w) and falls through to A<i+1>; the LAST event of a time step
+        leaves the chain for S<i>;
+  S<i>  ends the step (v += acc; any lane at threshold -> spike path, out of line; clip), then takes event i+1
+        as the first of the next step: its weights REPLACE the accumulator (no zeroing, no add: fmaf(c, w, +0)
+        equals c * w up to the sign of a zero, which v + acc cannot see because a clipped v is never -0).  If
+        event i+1 ends its step too, S<i+1> follows directly; else the code rejoins the first chain at A<i+2>.
+Per chunk: 16 x (address, LDS read(s)), wait, scalar prefetch of the next chunk into the other SGPR buffer, then
+SALU/VALU-only integration while the prefetch is in flight.  Chunks whose counts are all 1 (EV_CHUNK_MIXED
+clear) use plain adds; the others multiply by the count held in an SGPR.
+The arithmetic is the same sequence of f32 operations as the C++ path (integrate_chunk), so results are
+bit-identical.
+
+Operands: [v0..] membranes, [c0..] spike counters (in/out), [soff] byte offset of the current chunk (in/out,
+starts at 0), [nch] chunks left (in/out, >= 1), [ev] stream pointer, [lane] LDS byte address of this lane's first
+weights in row 0, [third] (three places) minus four times the lane number, [thr] 1 - 2^-24;
+temporaries [a0..] accumulator, [t], [t2], [ad0..ad3] addresses, [sc], [so] scalars.
+Clobbers: s[36:99] (the two chunk buffers), v[64:64+16*PPL) (the weights), vcc, scc.
+"""
+import os
+
+EA, EB = 36, 68                 # first SGPR of the two 32-word chunk buffers
+WPAIR, WTHIRD = 64, 96          # weights: event i -> v[64+2i : 65+2i] and (three places) v[96+i]
+EV_CHUNK = 16
+
+
+def gen(ppl):
+    hot, cold = [], []
+    V = [f"%[v{k}]" for k in range(ppl)]
+    C = [f"%[c{k}]" for k in range(ppl)]
+    A = [f"%[a{k}]" for k in range(ppl)]
+
+    def W(i):
+        regs = [f"v{WPAIR + 2 * i}", f"v{WPAIR + 2 * i + 1}"]
+        if ppl == 3:
+            regs.append(f"v{WTHIRD + i}")
+        return regs
+
+    def chunk(buf, other, name):
+        e = hot.append
+        off = lambda i: f"s{buf + 2 * i}"
+        cnt = lambda i: f"s{buf + 2 * i + 1}"
+        lab = lambda n: f"{n}{name}_%="
+
+        # ---- weight reads, next chunk's prefetch ----
+        e(f"s_and_b32 %[so], {off(0)}, 0x7fffffff")
+        for i in range(EV_CHUNK):
+            ad, ad2 = (f"%[ad{2 * (i & 1)}]", f"%[ad{2 * (i & 1) + 1}]")
+            e(f"v_add_u32 {ad}, {'%[so]' if i == 0 else off(i)}, %[lane]")
+            if ppl == 3:
+                e(f"v_add_u32 {ad2}, {ad}, %[third]")
+            e(f"ds_read_b64 v[{WPAIR + 2 * i}:{WPAIR + 2 * i + 1}], {ad}")
+            if ppl == 3:
+                e(f"ds_read_b32 v{WTHIRD + i}, {ad2} offset:512")
+        e("s_add_u32 %[soff], %[soff], 0x80")
+        e("s_sub_u32 %[nch], %[nch], 1")
+        e("s_cmp_eq_u32 %[nch], 0")
+        # LDS and scalar memory share one counter and scalar loads return out of order: the reads must have landed
+        # before the prefetch is issued, or waiting for them would wait for the prefetch as well
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_cbranch_scc1 {lab('NOPF')}")
+        e(f"s_load_dwordx16 s[{other}:{other + 15}], %[ev], %[soff] offset:0x0")
+        e(f"s_load_dwordx16 s[{other + 16}:{other + 31}], %[ev], %[soff] offset:0x40")
+        e(f"{lab('NOPF')}:")
+        e(f"s_bitcmp1_b32 {off(0)}, 31")
+        e(f"s_cbranch_scc1 {lab('A0M')}")
+
+        for mixed in (False, True):
+            m = "M" if mixed else ""
+            al = lambda i: lab(f"A{i}{m}") if i < EV_CHUNK else lab("END")
+
+            def count_to_sc(i, back):      # [sc] = count of event i as a float (flag bits cleared)
+                e(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
+                e("s_cmp_lt_u32 %[sc], 0x4b000000")
+                e(f"s_cbranch_scc0 {lab(f'BIG{back}')}")
+                e(f"{lab(f'BACK{back}')}:")
+                cold.append(f"{lab(f'BIG{back}')}:")          # count >= 2^23: its mantissa LSB is data, not a flag
+                cold.append(f"s_and_b32 %[sc], {cnt(i)}, 0x7fffffff")
+                cold.append(f"s_branch {lab(f'BACK{back}')}")
+
+            # ---- chain A ----
+            for i in range(EV_CHUNK):
+                e(f"{al(i)}:")
+                w = W(i)
+                if mixed:
+                    count_to_sc(i, f"A{i}")
+                    op = lambda k: f"v_fmac_f32 {A[k]}, %[sc], {w[k]}"
+                else:
+                    op = lambda k: f"v_add_f32 {A[k]}, {A[k]}, {w[k]}"
+                e(op(0))
+                e(f"s_cmp_gt_i32 {cnt(i)}, -1")
+                for k in range(1, ppl):
+                    e(op(k))
+                e(f"s_cbranch_scc0 {lab(f'S{i}{m}')}")
+            e(f"s_branch {lab('END')}")
+
+            # ---- chain S ----
+            for i in range(EV_CHUNK):
+                e(f"{lab(f'S{i}{m}')}:")
+                for k in range(ppl):
+                    e(f"v_add_f32 {V[k]}, {V[k]}, {A[k]}")
+                e(f"v_max3_f32 %[t], {V[0]}, {V[1]}, {V[2]}" if ppl == 3 else f"v_max_f32 %[t], {V[0]}, {V[1]}")
+                e("v_cmp_le_f32 vcc, %[thr], %[t]")
+                e(f"s_cbranch_vccnz {lab(f'SPK{i}{m}')}")
+                e(f"{lab(f'R{i}{m}')}:")
+                for k in range(ppl):
+                    e(f"v_fma_f32 {V[k]}, {V[k]}, 0.5, 0.5 clamp")
+                if i + 1 < EV_CHUNK and mixed:
+                    count_to_sc(i + 1, f"S{i}")
+                for k in range(ppl):
+                    e(f"v_fma_f32 {V[k]}, {V[k]}, 2.0, -1.0")
+                if i + 1 < EV_CHUNK:
+                    w = W(i + 1)
+                    e(f"s_cmp_gt_i32 {cnt(i + 1)}, -1")
+                    for k in range(ppl):
+                        e(f"v_mul_f32 {A[k]}, %[sc], {w[k]}" if mixed else f"v_mov_b32 {A[k]}, {w[k]}")
+                    e(f"s_cbranch_scc1 {al(i + 2)}")
+                else:
+                    for k in range(ppl):
+                        e(f"v_mov_b32 {A[k]}, 0")       # the step's successor is in the next chunk
+                    e(f"s_branch {lab('END')}")
+
+                # spike path of step i
+                c = cold.append
+                c(f"{lab(f'SPK{i}{m}')}:")
+                for k in range(ppl):
+                    c(f"v_max_f32 %[t], {V[k]}, {V[k]}")
+                    c("v_max_f32 %[t], 0, %[t]")
+                    c("v_floor_f32 %[t], %[t]")
+                    c(f"v_sub_f32 {V[k]}, {V[k]}, %[t]")
+                    c(f"v_add_f32 {C[k]}, {C[k]}, %[t]")
+                c(f"s_bitcmp0_b32 {cnt(i)}, 0")
+                c(f"s_cbranch_scc1 {lab(f'R{i}{m}')}")
+                if mixed:                               # the flag exists only on counts below 2^23
+                    c(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
+                    c("s_cmp_lt_u32 %[sc], 0x4b000000")
+                    c(f"s_cbranch_scc0 {lab(f'R{i}{m}')}")
+                # dropped empty steps follow: a membrane left at exactly 1.0 by the clip fires there
+                for k in range(ppl):
+                    c(f"v_fma_f32 %[t], {V[k]}, 0.5, 0.5 clamp")
+                    c("v_fma_f32 %[t], %[t], 2.0, -1.0")
+                    c(f"v_add_f32 %[t2], 1.0, {C[k]}")
+                    c("v_cmp_eq_f32 vcc, 1.0, %[t]")
+                    c("s_nop 1")
+                    c(f"v_cndmask_b32 {C[k]}, {C[k]}, %[t2], vcc")
+                    c(f"v_cndmask_b32_e64 {V[k]}, {V[k]}, 0, vcc")
+                c(f"s_branch {lab(f'R{i}{m}')}")
+
+        e(f"{lab('END')}:")
+        e("s_waitcnt lgkmcnt(0)")          # the next chunk's words
+        e("s_cmp_eq_u32 %[nch], 0")
+
+    e = hot.append
+    for k in range(ppl):
+        e(f"v_mov_b32 {A[k]}, 0")
+    e(f"s_load_dwordx16 s[{EA}:{EA + 15}], %[ev], %[soff] offset:0x0")
+    e(f"s_load_dwordx16 s[{EA + 16}:{EA + 31}], %[ev], %[soff] offset:0x40")
+    e("s_waitcnt lgkmcnt(0)")
+    e("LOOP_%=:")
+    chunk(EA, EB, "a")
+    e("s_cbranch_scc1 DONE_%=")
+    chunk(EB, EA, "b")
+    e("s_cbranch_scc0 LOOP_%=")
+    e("s_branch DONE_%=")
+    tail = ["DONE_%=:"]
+    return hot + cold + tail
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    for ppl in (2, 3):
+        path = os.path.join(here, "..", "lens_amd", "csrc", f"output_loop_p{ppl}.inc")
+        lines = gen(ppl)
+        with open(path, "w") as f:
+            f.write(f"// GENERATED by scripts/gen_output_loop.py -- do not edit.  gfx950 chunk loop of "
+                    f"k_output_counts<{ppl}, true>.\n")
+            for ln in lines:
+                f.write('"' + ln + '\\n"\n')
+        print(path, len(lines), "lines")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Generates lens_amd/csrc/output_loop_p{2,3}.inc: gfx950 assembly of k_output_counts' chunk loop for one query
-against an LDS weight tile of 128 (two places per lane) or 192 places (three per lane).  The generated files
+"""Generates lens_amd/csrc/output_loop_p{1,2,3,4}.inc: gfx950 assembly of k_output_counts' chunk loop for one query
+against an LDS weight tile of 64, 128, 192 or 256 places (one to four places per lane).  The generated files
 are committed; rerun this script after editing.
 
 Why assembly: the loop runs at the issue rate of its instruction mix (4 waves per SIMD next to the 100-150 KB
@@ -22,7 +22,8 @@ Operands: [v0..] membranes, [c0..] spike counters (in/out), [soff] byte offset o
 starts at 0), [nch] chunks left (in/out, >= 1), [ev] stream pointer, [lane] LDS byte address of this lane's first
 weights in row 0, [third] (three places) minus four times the lane number, [thr] 1 - 2^-24;
 temporaries [a0..] accumulator, [t], [t2], [ad0..ad3] addresses, [sc], [so] scalars.
-Clobbers: s[36:99] (the two chunk buffers), v[64:64+16*PPL) (the weights), vcc, scc.
+Clobbers: s[36:99] (the two chunk buffers), the weights' VGPRs (v64.. upwards: 16, 32 or 64 registers; three
+places: v[64:95] and v[96:111]), vcc, scc.
 """
 import os
 
@@ -38,10 +39,35 @@ def gen(ppl):
     A = [f"%[a{k}]" for k in range(ppl)]
 
     def W(i):
+        if ppl == 1:
+            return [f"v{WPAIR + i}"]
+        if ppl == 4:
+            return [f"v{WPAIR + 4 * i + k}" for k in range(4)]
         regs = [f"v{WPAIR + 2 * i}", f"v{WPAIR + 2 * i + 1}"]
         if ppl == 3:
             regs.append(f"v{WTHIRD + i}")
         return regs
+
+    def read(i, ad, ad2):
+        w = W(i)
+        if ppl == 1:
+            return [f"ds_read_b32 {w[0]}, {ad}"]
+        if ppl == 4:
+            return [f"ds_read_b128 v[{WPAIR + 4 * i}:{WPAIR + 4 * i + 3}], {ad}"]
+        r = [f"ds_read_b64 v[{WPAIR + 2 * i}:{WPAIR + 2 * i + 1}], {ad}"]
+        if ppl == 3:
+            r.append(f"ds_read_b32 {w[2]}, {ad2} offset:512")
+        return r
+
+    def fire_max():      # [t] = largest membrane of the lane's places (one place: the compare reads it directly)
+        if ppl == 1:
+            return [], V[0]
+        if ppl == 2:
+            return [f"v_max_f32 %[t], {V[0]}, {V[1]}"], "%[t]"
+        r = [f"v_max3_f32 %[t], {V[0]}, {V[1]}, {V[2]}"]
+        if ppl == 4:
+            r.append(f"v_max_f32 %[t], %[t], {V[3]}")
+        return r, "%[t]"
 
     def chunk(buf, other, name):
         e = hot.append
@@ -56,9 +82,8 @@ def gen(ppl):
             e(f"v_add_u32 {ad}, {'%[so]' if i == 0 else off(i)}, %[lane]")
             if ppl == 3:
                 e(f"v_add_u32 {ad2}, {ad}, %[third]")
-            e(f"ds_read_b64 v[{WPAIR + 2 * i}:{WPAIR + 2 * i + 1}], {ad}")
-            if ppl == 3:
-                e(f"ds_read_b32 v{WTHIRD + i}, {ad2} offset:512")
+            for ln in read(i, ad, ad2):
+                e(ln)
         e("s_add_u32 %[soff], %[soff], 0x80")
         e("s_sub_u32 %[nch], %[nch], 1")
         e("s_cmp_eq_u32 %[nch], 0")
@@ -106,8 +131,10 @@ def gen(ppl):
                 e(f"{lab(f'S{i}{m}')}:")
                 for k in range(ppl):
                     e(f"v_add_f32 {V[k]}, {V[k]}, {A[k]}")
-                e(f"v_max3_f32 %[t], {V[0]}, {V[1]}, {V[2]}" if ppl == 3 else f"v_max_f32 %[t], {V[0]}, {V[1]}")
-                e("v_cmp_le_f32 vcc, %[thr], %[t]")
+                mx, top = fire_max()
+                for ln in mx:
+                    e(ln)
+                e(f"v_cmp_le_f32 vcc, %[thr], {top}")
                 e(f"s_cbranch_vccnz {lab(f'SPK{i}{m}')}")
                 e(f"{lab(f'R{i}{m}')}:")
                 for k in range(ppl):
@@ -175,7 +202,7 @@ def gen(ppl):
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    for ppl in (2, 3):
+    for ppl in (1, 2, 3, 4):
         path = os.path.join(here, "..", "lens_amd", "csrc", f"output_loop_p{ppl}.inc")
         lines = gen(ppl)
         with open(path, "w") as f:

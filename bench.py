@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Benchmark of the LENS hot path on MI355X (contract: DESIGN.md "Measurement").
+"""Benchmark of the LENS hot path on MI355X.
 
 A step = one pass of the hot path over one batch of synthetic 128x128 event-count frames already
 resident in HBM:   frames -> rate-coded feature spike streams -> event-driven output layer (place
 database) -> sequence matcher + top-25 per query  [-> RCCL all-gather + merge when the database is
-sharded].  Metric: query event-frames/s (BASELINE.json), whole job.
+sharded].  Metric: query event-frames/s, whole job.
 
   python bench.py                              config 3: 100k-place DB, 4096 queries, 1 GPU (+ config 2, carried
                                                state and the CPU baseline as secondary objects of the same line)

@@ -4,8 +4,8 @@
  * the signatures (a HIP stream is passed as an opaque `void *`, 0 = the null stream).
  *
  * The reference (AdamDHines/LENS) is pure Python and has no FFI; each entry point below names
- * the reference code it replaces (paths relative to the reference repository).  INTEGRATION.md
- * shows the ctypes binding a LENS maintainer would add to call them.
+ * the reference code it replaces (paths relative to the reference repository); a LENS maintainer
+ * binds them with ctypes.
  *
  * Conventions
  *   - every `d_*` pointer is DEVICE memory owned by the caller; `h_*` pointers are host memory.
@@ -191,7 +191,7 @@ int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Q
 
 
 /* ---------------------------------------------------------------------------------------------
- * Training path (`python main.py --train_model`), SURVEY.md 8f-1 / BASELINE config 5.
+ * Training path (`python main.py --train_model`), the reference's training run (benchmark size: a 100 000-row output layer).
  * ------------------------------------------------------------------------------------------- */
 
 /* Padded fan-in the training kernel uses for n_in inputs (64/128/208/256/512/1024; 0 = n_in > 1024, unsupported).
@@ -241,7 +241,7 @@ int lens_sad_matrix(const uint8_t *d_query, int Q, const uint8_t *d_reference, i
 /*
  * DENSE variant of lens_output_counts on the f32 matrix cores (v_mfma_f32_32x32x2_f32), state reset per query.
  * Same replacement (lens/run_model.py:145,155,239) and bit-identical results (the f32 MFMA is a k-ordered fmaf
- * chain); kept as the measured "descriptor x database GEMM" comparison for DESIGN.md -- it is ~8x slower than the
+ * chain); kept as the measured "descriptor x database GEMM" comparison -- it is ~8x slower than the
  * event-driven kernel because it cannot skip the ~97% zero spikes.
  * d_featspk float [Q][T][ld_f] dense feature spike counts (lens_feature_events' optional output), F <= 256.
  */

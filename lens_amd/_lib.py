@@ -95,7 +95,7 @@ def lib():
 
 
 def check(status, what):
-    """Turn a C-ABI status into a Python exception (RuntimeError), like SURVEY 8b asks."""
+    """Turn a C-ABI status into a Python exception (LensAmdError, a RuntimeError)."""
     if status == 0:
         return
     if status < 0:

@@ -270,7 +270,7 @@ def topk_merge(idx_in, val_in, out=None):
 
 
 # --------------------------------------------------------------------------------------------
-# training path: thin wrappers over lens_layer_forward_clamped / lens_train_layer
+# training path (`--train_model`): thin wrappers over lens_layer_forward_clamped / lens_train_layer
 # --------------------------------------------------------------------------------------------
 def train_in_pad(n_in):
     pad = int(_lib.lib().lens_train_in_pad(int(n_in)))
@@ -325,7 +325,7 @@ def train_layer(w, thr, exc, inh, fire_rate, have_rate, x_table, order, eta_ip, 
 
 
 # --------------------------------------------------------------------------------------------
-# SAD baseline
+# SAD baseline (`--sad`)
 # --------------------------------------------------------------------------------------------
 def sad_matrix(query, reference):
     """L1 distance of every query frame to every reference frame (lens/src/sad.py:34-38).

@@ -1,4 +1,4 @@
-"""Event-list ingest: timestamped DVS events -> count frames on the GPU (SURVEY.md 8, rows a1 and f4).
+"""Event-list ingest: timestamped DVS events -> count frames on the GPU.
 
 The reference turns events into frames in one place, `create_images` of lens/collect_data.py:193-199: every
 `timebin` milliseconds the events received since the last call become one `roi x roi` frame

@@ -38,7 +38,7 @@ def format_table(field_names, row):
 
 def create_GTtol(GT, distance=2):
     """Ground truth with tolerance: binary dilation with a (2d+1)^2 square (run_model.py:272-289).
-    Host-side scipy, as in the reference (SURVEY.md 8a row a8)."""
+    Host-side scipy, as in the reference."""
     from scipy.ndimage import binary_dilation
     return binary_dilation(GT, structure=np.ones((2 * distance + 1, 2 * distance + 1), dtype=int)).astype(int)
 

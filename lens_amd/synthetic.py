@@ -1,4 +1,4 @@
-"""Synthetic inputs for the benchmark configurations (SURVEY.md 8d): event-count frames and a
+"""Synthetic inputs for the benchmark configurations: event-count frames and a
 large place database with the statistics of the bundled pretrained model.  Everything is drawn
 from seeded CPU generators so that the GPU path and the CPU oracle see identical inputs."""
 import numpy as np

@@ -1,4 +1,4 @@
-"""Training driver: host-side mirror of lens/train_model.py for the GPU path (SURVEY.md 8f-1).
+"""Training driver: host-side mirror of lens/train_model.py for the GPU path.
 
 Same surface as the reference (`LENS_Trainer(args)`, `.add_layer`, `.train_layer`, `.save_model`,
 `train_model(model, name)`, the saved state_dict keys), same layer-wise schedule: the feature layer is

@@ -1,5 +1,5 @@
-"""Training-step throughput of k_train_layer (BASELINE config 5): steps/s for the feature layer and for the
-output layer at P places, with the algorithmic HBM/ALU figures (development benchmark; see DESIGN.md)."""
+"""Training-step throughput of k_train_layer: steps/s for the feature layer and for the
+output layer at P places, with the algorithmic HBM/ALU figures (development benchmark)."""
 import argparse, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

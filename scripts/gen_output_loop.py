@@ -20,7 +20,8 @@ bit-identical.
 
 Operands: [v0..] membranes, [c0..] spike counters (in/out), [soff] byte offset of the current chunk (in/out,
 starts at 0), [nch] chunks left (in/out, >= 1), [ev] stream pointer, [lane] LDS byte address of this lane's first
-weights in row 0, [third] (three places) minus four times the lane number, [thr] 1 - 2^-24;
+weights in row 0, [third] (three places) minus four times the lane number, [thr] 1 - 2^-24 (a VGPR: a compare
+with an SGPR operand measured 3 % slower);
 temporaries [a0..] accumulator, [t], [t2], [ad0..ad3] addresses, [sc], [so] scalars.
 Clobbers: s[36:99] (the two chunk buffers), the weights' VGPRs (v64.. upwards: 16, 32 or 64 registers; three
 places: v[64:95] and v[96:111]), vcc, scc.
@@ -135,14 +136,15 @@ def gen(ppl):
                 for ln in mx:
                     e(ln)
                 e(f"v_cmp_le_f32 vcc, %[thr], {top}")
+                # first half of the clip into the (now dead) accumulator registers: covers the compare-to-branch latency
+                for k in range(ppl):
+                    e(f"v_fma_f32 {A[k]}, {V[k]}, 0.5, 0.5 clamp")
                 e(f"s_cbranch_vccnz {lab(f'SPK{i}{m}')}")
                 e(f"{lab(f'R{i}{m}')}:")
-                for k in range(ppl):
-                    e(f"v_fma_f32 {V[k]}, {V[k]}, 0.5, 0.5 clamp")
                 if i + 1 < EV_CHUNK and mixed:
                     count_to_sc(i + 1, f"S{i}")
                 for k in range(ppl):
-                    e(f"v_fma_f32 {V[k]}, {V[k]}, 2.0, -1.0")
+                    e(f"v_fma_f32 {V[k]}, {A[k]}, 2.0, -1.0")
                 if i + 1 < EV_CHUNK:
                     w = W(i + 1)
                     e(f"s_cmp_gt_i32 {cnt(i + 1)}, -1")
@@ -164,11 +166,11 @@ def gen(ppl):
                     c(f"v_sub_f32 {V[k]}, {V[k]}, %[t]")
                     c(f"v_add_f32 {C[k]}, {C[k]}, %[t]")
                 c(f"s_bitcmp0_b32 {cnt(i)}, 0")
-                c(f"s_cbranch_scc1 {lab(f'R{i}{m}')}")
+                c(f"s_cbranch_scc1 {lab(f'RC{i}{m}')}")
                 if mixed:                               # the flag exists only on counts below 2^23
                     c(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
                     c("s_cmp_lt_u32 %[sc], 0x4b000000")
-                    c(f"s_cbranch_scc0 {lab(f'R{i}{m}')}")
+                    c(f"s_cbranch_scc0 {lab(f'RC{i}{m}')}")
                 # dropped empty steps follow: a membrane left at exactly 1.0 by the clip fires there
                 for k in range(ppl):
                     c(f"v_fma_f32 %[t], {V[k]}, 0.5, 0.5 clamp")
@@ -178,6 +180,9 @@ def gen(ppl):
                     c("s_nop 1")
                     c(f"v_cndmask_b32 {C[k]}, {C[k]}, %[t2], vcc")
                     c(f"v_cndmask_b32_e64 {V[k]}, {V[k]}, 0, vcc")
+                c(f"{lab(f'RC{i}{m}')}:")                # the membranes changed: redo the first half of the clip
+                for k in range(ppl):
+                    c(f"v_fma_f32 {A[k]}, {V[k]}, 0.5, 0.5 clamp")
                 c(f"s_branch {lab(f'R{i}{m}')}")
 
         e(f"{lab('END')}:")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Golden vectors for the `--PR_curve` / `--sad` rows, from the reference's own
+"""Golden vectors for the `--PR_curve` / `--sad` paths, from the reference's own
 lens/src/metrics.py::createPR (imported as is) and lens/src/sad.py::run_sad (skimage.io.imread -> PIL stub,
 IO only).  Inputs: the similarity matrix / GT of the bundled example run (tests/golden/example.npz) and the
 bundled example PNG folders.   Usage: python tests/golden/make_golden_pr.py -> tests/golden/pr_sad.npz"""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-Golden vectors for the training path (BASELINE config 5), produced by the REFERENCE's
+Golden vectors for the training path, produced by the REFERENCE's
 own code: lens/train_model.py (LENS_Trainer, train_layer, _anneal_learning_rate), lens/src/blitnet.py
 (SNNLayer training-mode init, clamp_spikes, calc_stdp) and lens/src/dataset.py (CustomImageDataset with
 test=False + ProcessImage(is_train=True)), imported from /root/reference in the build container.

@@ -1,4 +1,4 @@
-"""Full BASELINE sizes (config 3: 100 000 places, 4096 queries of 128x128 synthetic frames, T=250, L=2,
+"""Full benchmark sizes (100 000 places, 4096 queries of 128x128 synthetic frames, T=250, L=2,
 top-25) through the C ABI.  The oracle cannot run this size, so the checks are the size-independent
 properties of the path, plus exact oracle parity on a scattered sample:
 

@@ -133,7 +133,7 @@ def test_real_density_sampled_parity_against_20000_places(O):
 
 
 def test_training_100000_rows_sampled_against_the_oracle(O):
-    """BASELINE config 5 size: 300 spike-forcing steps of a [100 000 x 200] output layer on the GPU; weight rows
+    """Benchmark training size: 300 spike-forcing steps of a [100 000 x 200] output layer on the GPU; weight rows
     evolve independently given the sample sequence, so 64 scattered rows (and the forced ones among them) must equal
     the oracle run on exactly those rows."""
     from lens_amd.engine import train_layer, train_in_pad, pad_table

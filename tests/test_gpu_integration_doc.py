@@ -1,5 +1,5 @@
-"""INTEGRATION.md section 2 shows the ctypes stub a LENS maintainer would add.  This test executes exactly that
-code block (library path patched) on both bundled data sets and compares with the golden vectors of the
+"""The integration guide at the repository root shows the ctypes stub a LENS maintainer would add.  This test
+executes exactly that code block (library path patched) on both bundled data sets and compares with the golden vectors of the
 reference run, so the documented binding cannot rot."""
 import os
 import re

@@ -1,4 +1,4 @@
-"""GPU parity of the training kernels: bit-exact against the oracle and against the golden run
+"""GPU parity of the training kernels : bit-exact against the oracle and against the golden run
 of the reference's own train_model.py/blitnet.py with the Linear's summation order pinned to the chain."""
 import numpy as np
 import pytest

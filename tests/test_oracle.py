@@ -135,7 +135,7 @@ def test_accumulate_events_follows_torch_indexing():
 
 
 # ---------------------------------------------------------------------------------------------
-# training path (SURVEY 8f-1): goldens come from the reference's own lens/train_model.py + blitnet.py
+# training path: goldens come from the reference's own lens/train_model.py + blitnet.py
 # ---------------------------------------------------------------------------------------------
 def _train_replay(G, upto=None):
     """Replay the golden run with the oracle; yields (layer, step, w, thr) at the golden snapshot steps."""

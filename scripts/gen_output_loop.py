@@ -14,7 +14,8 @@ compiler's control-flow structurizer turns it into flag bookkeeping.  The shape 
         event i+1 ends its step too, S<i+1> follows directly; else the code rejoins the first chain at A<i+2>.
 Per chunk: 16 x (address, LDS read(s)), wait, scalar prefetch of the next chunk into the other SGPR buffer, then
 SALU/VALU-only integration while the prefetch is in flight.  Chunks whose counts are all 1 (EV_CHUNK_MIXED
-clear) use plain adds; the others multiply by the count held in an SGPR.
+clear) use plain adds; the others multiply by the count held in an SGPR, in a variant without the per-event test for
+counts of 2^23 and more when the OR of the chunk's count words rules those out.
 The arithmetic is the same sequence of f32 operations as the C++ path (integrate_chunk), so results are
 bit-identical.
 
@@ -96,20 +97,33 @@ def gen(ppl):
         e(f"s_load_dwordx16 s[{other + 16}:{other + 31}], %[ev], %[soff] offset:0x40")
         e(f"{lab('NOPF')}:")
         e(f"s_bitcmp1_b32 {off(0)}, 31")
-        e(f"s_cbranch_scc1 {lab('A0M')}")
+        e(f"s_cbranch_scc1 {lab('MIXED')}")
+        # A chunk with counts other than 1: is any of them 2^23 or more (mantissa LSB = data, not the EV_EMPTY_NEXT
+        # flag)?  The OR of the 16 count words is below 0x4b000000 only if every count is (a few combinations of
+        # counts from 2^21 up test positive as well and take the careful variant, which is correct for any chunk).
+        c = cold.append
+        c(f"{lab('MIXED')}:")
+        c(f"s_or_b32 %[sc], {cnt(0)}, {cnt(1)}")
+        for i in range(2, EV_CHUNK):
+            c(f"s_or_b32 %[sc], %[sc], {cnt(i)}")
+        c("s_and_b32 %[sc], %[sc], 0x7fffffff")
+        c("s_cmp_lt_u32 %[sc], 0x4b000000")
+        c(f"s_cbranch_scc1 {lab('A0M')}")
+        c(f"s_branch {lab('A0H')}")
 
-        for mixed in (False, True):
-            m = "M" if mixed else ""
+        for m in ("", "M", "H"):     # counts all 1 / all below 2^23 / any
+            mixed = m != ""
             al = lambda i: lab(f"A{i}{m}") if i < EV_CHUNK else lab("END")
 
             def count_to_sc(i, back):      # [sc] = count of event i as a float (flag bits cleared)
                 e(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
-                e("s_cmp_lt_u32 %[sc], 0x4b000000")
-                e(f"s_cbranch_scc0 {lab(f'BIG{back}')}")
-                e(f"{lab(f'BACK{back}')}:")
-                cold.append(f"{lab(f'BIG{back}')}:")          # count >= 2^23: its mantissa LSB is data, not a flag
-                cold.append(f"s_and_b32 %[sc], {cnt(i)}, 0x7fffffff")
-                cold.append(f"s_branch {lab(f'BACK{back}')}")
+                if m == "H":
+                    e("s_cmp_lt_u32 %[sc], 0x4b000000")
+                    e(f"s_cbranch_scc0 {lab(f'BIG{back}')}")
+                    e(f"{lab(f'BACK{back}')}:")
+                    cold.append(f"{lab(f'BIG{back}')}:")      # count >= 2^23: its mantissa LSB is data, not a flag
+                    cold.append(f"s_and_b32 %[sc], {cnt(i)}, 0x7fffffff")
+                    cold.append(f"s_branch {lab(f'BACK{back}')}")
 
             # ---- chain A ----
             for i in range(EV_CHUNK):
@@ -167,7 +181,7 @@ def gen(ppl):
                     c(f"v_add_f32 {C[k]}, {C[k]}, %[t]")
                 c(f"s_bitcmp0_b32 {cnt(i)}, 0")
                 c(f"s_cbranch_scc1 {lab(f'RC{i}{m}')}")
-                if mixed:                               # the flag exists only on counts below 2^23
+                if m == "H":                            # the flag exists only on counts below 2^23
                     c(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
                     c("s_cmp_lt_u32 %[sc], 0x4b000000")
                     c(f"s_cbranch_scc0 {lab(f'RC{i}{m}')}")

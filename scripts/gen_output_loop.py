@@ -32,6 +32,7 @@ import os
 EA, EB = 36, 68                 # first SGPR of the two 32-word chunk buffers
 WPAIR, WTHIRD = 64, 96          # weights: event i -> v[64+2i : 65+2i] and (three places) v[96+i]
 EV_CHUNK = 16
+PAIR_FIRST = True               # a step's first two events enter the accumulator with one add per place
 
 
 def gen(ppl):
@@ -142,7 +143,10 @@ def gen(ppl):
             e(f"s_branch {lab('END')}")
 
             # ---- chain S ----
-            for i in range(EV_CHUNK):
+            pair_first = PAIR_FIRST and not mixed
+            order = (list(range(0, EV_CHUNK, 2)) + list(range(1, EV_CHUNK, 2))) if pair_first else list(range(EV_CHUNK))
+            for pos, i in enumerate(order):
+                nxt = order[pos + 1] if pos + 1 < EV_CHUNK else None     # the block laid out after this one
                 e(f"{lab(f'S{i}{m}')}:")
                 for k in range(ppl):
                     e(f"v_add_f32 {V[k]}, {V[k]}, {A[k]}")
@@ -150,25 +154,48 @@ def gen(ppl):
                 for ln in mx:
                     e(ln)
                 e(f"v_cmp_le_f32 vcc, %[thr], {top}")
-                # first half of the clip into the (now dead) accumulator registers: covers the compare-to-branch latency
+                # first half of the clip into the (now dead) accumulator registers, between the compare and its branch
                 for k in range(ppl):
                     e(f"v_fma_f32 {A[k]}, {V[k]}, 0.5, 0.5 clamp")
                 e(f"s_cbranch_vccnz {lab(f'SPK{i}{m}')}")
                 e(f"{lab(f'R{i}{m}')}:")
                 if i + 1 < EV_CHUNK and mixed:
                     count_to_sc(i + 1, f"S{i}")
-                for k in range(ppl):
-                    e(f"v_fma_f32 {V[k]}, {A[k]}, 2.0, -1.0")
-                if i + 1 < EV_CHUNK:
-                    w = W(i + 1)
+                if pair_first and i + 2 < EV_CHUNK:
+                    # Events i+1 and i+2 open the next step together: acc = w[i+1] + w[i+2] (fl(fl(0 + a) + b) is
+                    # fl(a + b)), one add per place instead of a move and an add.  A step of a single event (16 % at
+                    # the benchmark's density) takes the move, out of line.
+                    w1, w2 = W(i + 1), W(i + 2)
                     e(f"s_cmp_gt_i32 {cnt(i + 1)}, -1")
                     for k in range(ppl):
-                        e(f"v_mul_f32 {A[k]}, %[sc], {w[k]}" if mixed else f"v_mov_b32 {A[k]}, {w[k]}")
-                    e(f"s_cbranch_scc1 {al(i + 2)}")
+                        e(f"v_fma_f32 {V[k]}, {A[k]}, 2.0, -1.0")
+                    e(f"s_cbranch_scc0 {lab(f'ONE{i}')}")
+                    e(f"v_add_f32 {A[0]}, {w1[0]}, {w2[0]}")
+                    e(f"s_cmp_gt_i32 {cnt(i + 2)}, -1")
+                    for k in range(1, ppl):
+                        e(f"v_add_f32 {A[k]}, {w1[k]}, {w2[k]}")
+                    e(f"s_cbranch_scc1 {al(i + 3)}")
+                    if nxt != i + 2:
+                        e(f"s_branch {lab(f'S{i + 2}{m}')}")
+                    cold.append(f"{lab(f'ONE{i}')}:")
+                    for k in range(ppl):
+                        cold.append(f"v_mov_b32 {A[k]}, {w1[k]}")
+                    cold.append(f"s_branch {lab(f'S{i + 1}{m}')}")
                 else:
                     for k in range(ppl):
-                        e(f"v_mov_b32 {A[k]}, 0")       # the step's successor is in the next chunk
-                    e(f"s_branch {lab('END')}")
+                        e(f"v_fma_f32 {V[k]}, {A[k]}, 2.0, -1.0")
+                    if i + 1 < EV_CHUNK:
+                        w = W(i + 1)
+                        e(f"s_cmp_gt_i32 {cnt(i + 1)}, -1")
+                        for k in range(ppl):
+                            e(f"v_mul_f32 {A[k]}, %[sc], {w[k]}" if mixed else f"v_mov_b32 {A[k]}, {w[k]}")
+                        e(f"s_cbranch_scc1 {al(i + 2)}")
+                        if nxt != i + 1:
+                            e(f"s_branch {lab(f'S{i + 1}{m}')}")
+                    else:
+                        for k in range(ppl):
+                            e(f"v_mov_b32 {A[k]}, 0")       # the step's successor is in the next chunk
+                        e(f"s_branch {lab('END')}")
 
                 # spike path of step i
                 c = cold.append

@@ -150,6 +150,7 @@ def gen(ppl):
                 e(f"{lab(f'S{i}{m}')}:")
                 for k in range(ppl):
                     e(f"v_add_f32 {V[k]}, {V[k]}, {A[k]}")
+                e(f"{lab(f'SM{i}{m}')}:")                  # entry for a step of one event: its weights went straight to v
                 mx, top = fire_max()
                 for ln in mx:
                     e(ln)
@@ -179,8 +180,8 @@ def gen(ppl):
                         e(f"s_branch {lab(f'S{i + 2}{m}')}")
                     cold.append(f"{lab(f'ONE{i}')}:")
                     for k in range(ppl):
-                        cold.append(f"v_mov_b32 {A[k]}, {w1[k]}")
-                    cold.append(f"s_branch {lab(f'S{i + 1}{m}')}")
+                        cold.append(f"v_add_f32 {V[k]}, {V[k]}, {w1[k]}")
+                    cold.append(f"s_branch {lab(f'SM{i + 1}{m}')}")
                 else:
                     for k in range(ppl):
                         e(f"v_fma_f32 {V[k]}, {A[k]}, 2.0, -1.0")

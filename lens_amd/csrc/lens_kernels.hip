@@ -14,8 +14,11 @@
 // are the explicit __builtin_fmaf calls.
 //
 // Reference lines each kernel replaces are cited in include/lens_amd.h.
-// feature_loop_n2f4.inc (generated by scripts/gen_feature_loop.py) is the hand-scheduled gfx950 assembly of
-// k_feature_events' step loop for the 65..128-input / 129..256-feature instantiation; every other path is HIP C++.
+// Generated gfx950 assembly, included as asm statements: feature_loop_n2f4.inc (scripts/gen_feature_loop.py), the step
+// loop of k_feature_events for the 65..128-input / 129..256-feature instantiation, and output_loop_p{1..4}.inc
+// (scripts/gen_output_loop.py), the chunk loop of k_output_counts for the four LDS tile widths.  The per-weight
+// sections of the training kernels are blocks of instructions written out in this file.  Every path also exists in
+// HIP C++ (other instantiations, the through-L2 variant), which documents the arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -399,7 +402,7 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
 // a5-a6. spike streams -> output spike counts.
 //   A workgroup owns a tile of PT = 64*PPL places (their W2^T columns staged in LDS once) and a
 //   group of queries; each wavefront integrates whole queries against the tile, one lane =
-//   PPL consecutive places, membrane potentials and spike counters in registers, the T-step
+//   PPL places (lane_place), membrane potentials and spike counters in registers, the T-step
 //   loop inside the kernel.  The stream is read with scalar loads, 16 words at a time.
 // ------------------------------------------------------------------------------------------
 struct OutArgs {

@@ -955,9 +955,9 @@ __global__ void __launch_bounds__(256) k_topk_merge(const int32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // f1. Training (`--train_model`): lens/train_model.py:157-177 + calc_stdp, lens/src/blitnet.py:183-254.
 //   Every output neuron of a layer evolves independently given the sample sequence (its forward value,
-//   STDP row, threshold and homeostasis only involve its own weight row), so one LANE owns one row,
-//   keeps it in registers for all T steps and the per-step input vector is wave-uniform (scalar loads).
-//   IN_PAD: padded fan-in (registers per lane); x_table / mpre_table rows are zero padded to ldx >= IN_PAD.
+//   STDP row, threshold and homeostasis only involve its own weight row), so 1, 2, 4 or 8 adjacent lanes own one
+//   row, keep it in registers for all T steps, and the per-step input vector is staged through LDS.  Per-element sign
+//   masks are kept as packed bits.  IN_PAD: padded fan-in; x_table / mpre_table rows are zero padded to ldx >= IN_PAD.
 // ------------------------------------------------------------------------------------------
 struct TrainArgs {
     float *w; int ldw;
@@ -980,14 +980,6 @@ __device__ __forceinline__ void stage_row(const float *row, float *lds, int lane
         const int c = base + lane * 4;
         if (c < IN_PAD) *reinterpret_cast<float4 *>(lds + c) = *reinterpret_cast<const float4 *>(row + c);
     }
-}
-
-// Per-element sign masks are kept as packed bits; selects are integer blends (v_bfe_i32 gives an all-ones /
-// all-zeros word, v_bfi_b32 blends), so no per-element lane masks (SGPR pairs) are ever materialised.
-__device__ __forceinline__ uint32_t bit_mask(uint32_t word, int n) { return (uint32_t)__builtin_amdgcn_sbfe((int)word, n & 31, 1); }
-__device__ __forceinline__ float blend(uint32_t m, float a, float b)   // m ? a : b, bitwise
-{
-    return __uint_as_float((m & __float_as_uint(a)) | (~m & __float_as_uint(b)));
 }
 
 // value of the lane to the left (lane - 1) via DPP row_shr:1 (rows of 16 lanes; the first lane of a row gets 0)

@@ -555,16 +555,14 @@ __device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], c
 #define LENS_OUT_V112_127                                                                                                \
     "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 #define LENS_OUT_COMMON_OUT                                                                                              \
-    [soff] "+&s"(soff), [nch] "+&s"(nch), [t] "=&v"(t), [t2] "=&v"(t2), [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),              \
-    [ad2] "=&v"(ad2), [ad3] "=&v"(ad3), [ad4] "=&v"(ad4), [ad5] "=&v"(ad5), [ad6] "=&v"(ad6), [ad7] "=&v"(ad7),          \
-    [sc] "=&s"(sc), [so] "=&s"(so)
+    [soff] "+&s"(soff), [nch] "+&s"(nch), [t] "=&v"(t), [t2] "=&v"(t2), [sc] "=&s"(sc), [so] "=&s"(so)
 #define LENS_OUT_COMMON_IN [ev] "s"(ev), [lane] "v"(lane_addr), [third] "v"(third), [thr] "v"(thr)
 template <int PPL>
 __device__ __forceinline__ void output_loop_asm(const uint32_t *ev, uint32_t nch, uint32_t lane_addr, uint32_t third,
                                                 float (&v)[PPL], float (&cnt)[PPL])
 {
     static_assert(PPL >= 1 && PPL <= 4, "generated for one to four places per lane");
-    uint32_t soff = 0, sc, so, ad0, ad1, ad2, ad3, ad4, ad5, ad6, ad7;
+    uint32_t soff = 0, sc, so;
     float a[PPL], t, t2;
     const float thr = 0.99999994f;   // 1 - 2^-24: the clip rounds it up to exactly 1.0
     if constexpr (PPL == 1) {

@@ -23,7 +23,7 @@ Operands: [v0..] membranes, [c0..] spike counters (in/out), [soff] byte offset o
 starts at 0), [nch] chunks left (in/out, >= 1), [ev] stream pointer, [lane] LDS byte address of this lane's first
 weights in row 0, [third] (three places) minus four times the lane number, [thr] 1 - 2^-24 (a VGPR: a compare
 with an SGPR operand measured 3 % slower);
-temporaries [a0..] accumulator, [t], [t2], [ad0..ad7] addresses, [sc], [so] scalars.
+temporaries [a0..] accumulator, [t], [t2], [sc], [so] scalars.
 Clobbers: s[36:99] (the two chunk buffers), the weights' VGPRs (v64.. upwards: 16, 32 or 64 registers; three
 places: v[64:95] and v[96:111]), vcc, scc.
 """
@@ -32,7 +32,7 @@ import os
 EA, EB = 36, 68                 # first SGPR of the two 32-word chunk buffers
 WPAIR, WTHIRD = 64, 96          # weights: event i -> v[64+2i : 65+2i] and (three places) v[96+i]
 EV_CHUNK = 16
-READ_GROUP = 4                  # events whose addresses are computed before their reads are issued
+READ_GROUP = 16                 # events whose addresses are computed before their reads are issued
 PAIR_FIRST = True               # a step's first two events enter the accumulator with one add per place
 
 
@@ -81,19 +81,18 @@ def gen(ppl):
 
         # ---- weight reads, next chunk's prefetch ----
         e(f"s_and_b32 %[so], {off(0)}, 0x7fffffff")
-        # READ_GROUP events at a time: their addresses first, then their reads by kind, so that no read waits for
-        # the add right before it (same-box: groups of two -1.9 %, of four -2.8 %; computing the next group's addresses
-        # between this group's reads on top of that: no further gain)
+        # Every weight register first holds the address of its own read (a read may overwrite its address register:
+        # the address is consumed when the read issues), so all addresses are computed before the first read is
+        # issued and no read waits for the add right before it.  Same-box, against the address right before its
+        # read: groups of two events -1.9 %, of four, eight or all sixteen -2.8 %.
         for i0 in range(0, EV_CHUNK, READ_GROUP):
-            ads = []
-            for g, i in enumerate(range(i0, i0 + READ_GROUP)):
-                ad, ad2 = f"%[ad{2 * g}]", f"%[ad{2 * g + 1}]"
-                ads.append((i, ad, ad2))
-                e(f"v_add_u32 {ad}, {'%[so]' if i == 0 else off(i)}, %[lane]")
+            ev = list(range(i0, min(EV_CHUNK, i0 + READ_GROUP)))
+            for i in ev:
+                e(f"v_add_u32 {W(i)[0]}, {'%[so]' if i == 0 else off(i)}, %[lane]")
             if ppl == 3:
-                for i, ad, ad2 in ads:
-                    e(f"v_add_u32 {ad2}, {ad}, %[third]")
-            lines = [read(i, ad, ad2) for i, ad, ad2 in ads]
+                for i in ev:
+                    e(f"v_add_u32 {W(i)[2]}, {W(i)[0]}, %[third]")
+            lines = [read(i, W(i)[0], W(i)[2] if ppl == 3 else None) for i in ev]
             for k in range(max(len(l) for l in lines)):
                 for l in lines:
                     if k < len(l):

@@ -64,4 +64,6 @@ for case in range(n_cases):
             print(" gpu idx", g[r].tolist()); print(" ref idx", oi[r].tolist()); print(" gpu val", gvv[r].tolist()); print(" ref val", ov[r].tolist())
             print(" S col", S[:, r].tolist()[:80])
             sys.exit(1)
+    if case % 10 == 9:
+        print(f"  {case + 1} cases, {time.time() - t0:.0f} s", flush=True)
 print(f"{n_cases} cases ok in {time.time() - t0:.1f} s")

@@ -194,7 +194,7 @@ int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Q
  * Training path (`python main.py --train_model`), the reference's training run (benchmark size: a 100 000-row output layer).
  * ------------------------------------------------------------------------------------------- */
 
-/* Padded fan-in the training kernel uses for n_in inputs (64/128/208/256/512/1024; 0 = n_in > 1024, unsupported).
+/* Padded fan-in the training kernel uses for n_in inputs (64/128/200/208/256/512/1024; 0 = n_in > 1024, unsupported).
  * x_table / mpre_table rows must be zero padded to a leading dimension >= this value. */
 int lens_train_in_pad(int n_in);
 

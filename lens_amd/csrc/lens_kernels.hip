@@ -1261,7 +1261,8 @@ __device__ __forceinline__ void train_layer_body(const TrainArgs &a)
     {                                                                                                     \
         train_layer_body<P, LPR, SPK>(a);                                                                 \
     }
-LENS_TRAIN_KERNEL(64, 1, 5) LENS_TRAIN_KERNEL(128, 1, 3) LENS_TRAIN_KERNEL(128, 2, 5) LENS_TRAIN_KERNEL(208, 1, 2)
+LENS_TRAIN_KERNEL(64, 1, 5) LENS_TRAIN_KERNEL(128, 1, 3) LENS_TRAIN_KERNEL(128, 2, 5) LENS_TRAIN_KERNEL(200, 1, 2)
+LENS_TRAIN_KERNEL(200, 2, 3) LENS_TRAIN_KERNEL(208, 1, 2)
 LENS_TRAIN_KERNEL(208, 2, 3) LENS_TRAIN_KERNEL(208, 4, 5) LENS_TRAIN_KERNEL(256, 2, 3) LENS_TRAIN_KERNEL(256, 4, 5)
 LENS_TRAIN_KERNEL(512, 4, 3) LENS_TRAIN_KERNEL(512, 8, 5) LENS_TRAIN_KERNEL(1024, 8, 3)
 #undef LENS_TRAIN_KERNEL
@@ -1675,7 +1676,7 @@ int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Q
 
 int lens_train_in_pad(int n_in)
 {
-    for (int p : {64, 128, 208, 256, 512, 1024})
+    for (int p : {64, 128, 200, 208, 256, 512, 1024})   // 200: the default LENS feature count (2 x 10 x 10), no padding
         if (n_in <= p) return p;
     return 0;
 }
@@ -1705,6 +1706,7 @@ static int train_lanes_per_row(int pad, int n_out)
     switch (pad) {
     case 64: lo = 1; hi = 1; break;
     case 128: lo = 1; hi = 2; break;
+    case 200: lo = 1; hi = 2; break;
     case 208: lo = 1; hi = 4; break;
     case 256: lo = 2; hi = 4; break;
     case 512: lo = 4; hi = 8; break;
@@ -1757,7 +1759,8 @@ int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, co
         return (int)hipGetLastError();                                                                   \
     }
     const int lpr = train_lanes_per_row(pad, n_out);
-    LENS_TRAIN_CASE(64, 1) LENS_TRAIN_CASE(128, 1) LENS_TRAIN_CASE(128, 2) LENS_TRAIN_CASE(208, 1) LENS_TRAIN_CASE(208, 2)
+    LENS_TRAIN_CASE(64, 1) LENS_TRAIN_CASE(128, 1) LENS_TRAIN_CASE(128, 2) LENS_TRAIN_CASE(200, 1) LENS_TRAIN_CASE(200, 2)
+    LENS_TRAIN_CASE(208, 1) LENS_TRAIN_CASE(208, 2)
     LENS_TRAIN_CASE(208, 4) LENS_TRAIN_CASE(256, 2) LENS_TRAIN_CASE(256, 4) LENS_TRAIN_CASE(512, 4) LENS_TRAIN_CASE(512, 8)
     LENS_TRAIN_CASE(1024, 8)
 #undef LENS_TRAIN_CASE

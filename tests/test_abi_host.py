@@ -296,8 +296,8 @@ def test_training_pad_covers_wide_layers_and_short_csv_annealing():
     from lens_amd import _lib
     from lens_amd.train_model import anneal_schedule
     L = _lib.lib()
-    assert [L.lens_train_in_pad(n) for n in (1, 64, 65, 200, 256, 257, 800, 1024, 1025)] == \
-        [64, 64, 128, 208, 256, 512, 1024, 1024, 0]
+    assert [L.lens_train_in_pad(n) for n in (1, 64, 65, 200, 201, 256, 257, 800, 1024, 1025)] == \
+        [64, 64, 128, 200, 208, 256, 512, 1024, 1024, 0]
 
     class Layer:
         eta_ip = torch.tensor(0.02)

@@ -222,8 +222,7 @@ def gen(ppl):
                 c = cold.append
                 c(f"{lab(f'SPK{i}{m}')}:")
                 for k in range(ppl):
-                    c(f"v_max_f32 %[t], {V[k]}, {V[k]}")
-                    c("v_max_f32 %[t], 0, %[t]")
+                    c(f"v_max_f32 %[t], 0, {V[k]}")      # a NaN membrane (never a signalling one: it is a sum) gives 0
                     c("v_floor_f32 %[t], %[t]")
                     c(f"v_sub_f32 {V[k]}, {V[k]}, %[t]")
                     c(f"v_add_f32 {C[k]}, {C[k]}, %[t]")

@@ -55,6 +55,7 @@ constexpr uint32_t EV_CHUNK_MIXED = 0x80000000u;
 constexpr int EV_CHUNK = 16;
 constexpr int EV_WORDS = 2 * EV_CHUNK;
 constexpr int OUT_ORDER_MAX = 512;    // largest query group the output kernel sorts by stream length
+constexpr int OUT_BOOK_BYTES = OUT_ORDER_MAX * 6 + 16;   // its lengths, order and query counter, behind the LDS tile
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 {
@@ -420,7 +421,10 @@ template <> struct VecT<4> { using type = float4; };
 
 // Place (within the tile) of component k of a lane.  PPL = 3 splits the 192-place tile row into a 128-place part read
 // as one 8-byte word per lane and a 64-place part read as one 4-byte word per lane (a 12-byte read per lane would not
-// be aligned and runs at a fraction of the LDS rate).
+// be aligned and runs at a fraction of the LDS rate).  In LDS the two parts are separate planes: [F][64] floats of
+// the third places at the start of the workgroup's LDS, then [F][128] floats of the pairs; an event word (row x 512)
+// addresses the pairs directly and the thirds after a shift by one (ds_read_addtid_b32: M0 + 4 x lane, no vector
+// address).
 template <int PPL>
 __device__ __forceinline__ int lane_place(int lane, int k)
 {
@@ -442,28 +446,20 @@ __device__ __forceinline__ void vec_unpack(const typename VecT<PPL>::type &x, fl
 // lgkmcnt(0) and wait for the prefetch too.
 template <int PPL, bool W_LDS>
 __device__ __forceinline__ void load_weights(const uint32_t (&e)[EV_WORDS], const unsigned char *smem, const float *w2t,
-                                             int ldw, int pl, uint32_t lane_off, uint32_t third_off,
-                                             float (&w)[EV_CHUNK][PPL])
+                                             int ldw, int pl, uint32_t lane_off, float (&w)[EV_CHUNK][PPL])
 {
+    static_assert(PPL != 3, "three places per lane exist in the assembly loop only");
 #pragma unroll
     for (int i = 0; i < EV_CHUNK; ++i) {
         const uint32_t off = i ? e[2 * i] : (e[0] & ~EV_CHUNK_MIXED);
-        if constexpr (PPL == 3) {
-            static_assert(W_LDS, "three places per lane exist for the LDS tile only");
-            const unsigned char *row = smem + (off + lane_off);           // lane_off = 8 * lane
-            const float2 ab = *reinterpret_cast<const float2 *>(row);
-            w[i][0] = ab.x; w[i][1] = ab.y;
-            w[i][2] = *reinterpret_cast<const float *>(row + third_off);   // third_off = 512 - 4 * lane
+        using vec_t = typename VecT<PPL>::type;
+        vec_t wv;
+        if constexpr (W_LDS) {
+            wv = *reinterpret_cast<const vec_t *>(smem + (off + lane_off));
         } else {
-            using vec_t = typename VecT<PPL>::type;
-            vec_t wv;
-            if constexpr (W_LDS) {
-                wv = *reinterpret_cast<const vec_t *>(smem + (off + lane_off));
-            } else {
-                wv = *reinterpret_cast<const vec_t *>(w2t + (size_t)off * ldw + pl);
-            }
-            vec_unpack<PPL>(wv, w[i]);
+            wv = *reinterpret_cast<const vec_t *>(w2t + (size_t)off * ldw + pl);
         }
+        vec_unpack<PPL>(wv, w[i]);
     }
 }
 
@@ -474,18 +470,12 @@ __device__ __forceinline__ void load_weights(const uint32_t (&e)[EV_WORDS], cons
 template <int PPL>
 __device__ __forceinline__ uint32_t weights_token(const float (&w)[EV_CHUNK][PPL])
 {
-    // one read instruction per event returns all components (the first two for PPL = 3), so the first component of
-    // every event covers them
+    // one read instruction per event returns all components, so the first component of every event covers them
     uint32_t tok;
     static_assert(EV_CHUNK == 16, "operand list below");
     asm("s_mov_b32 %0, 0" : "=s"(tok)
         : "v"(w[0][0]), "v"(w[1][0]), "v"(w[2][0]), "v"(w[3][0]), "v"(w[4][0]), "v"(w[5][0]), "v"(w[6][0]), "v"(w[7][0]),
           "v"(w[8][0]), "v"(w[9][0]), "v"(w[10][0]), "v"(w[11][0]), "v"(w[12][0]), "v"(w[13][0]), "v"(w[14][0]), "v"(w[15][0]));
-    if constexpr (PPL == 3) {   // the third place comes from a read instruction of its own
-        asm("s_mov_b32 %0, 0" : "+s"(tok)
-            : "v"(w[0][2]), "v"(w[1][2]), "v"(w[2][2]), "v"(w[3][2]), "v"(w[4][2]), "v"(w[5][2]), "v"(w[6][2]), "v"(w[7][2]),
-              "v"(w[8][2]), "v"(w[9][2]), "v"(w[10][2]), "v"(w[11][2]), "v"(w[12][2]), "v"(w[13][2]), "v"(w[14][2]), "v"(w[15][2]));
-    }
     return tok;
 }
 
@@ -542,7 +532,8 @@ __device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], c
 
 // The chunk loop of one query in gfx950 assembly (scripts/gen_output_loop.py), for the LDS tiles: same f32 operations in
 // the same order as integrate_chunk, laid out as two chains of code that C++ cannot express without flag bookkeeping.
-// `lane_addr` = LDS byte address of this lane's first weights in row 0 of the tile.
+// `lane_addr` = LDS byte address of this lane's first weights in row 0 of the tile (three places per lane: of its
+// pair of places; the third place is read through M0 from the plane at LDS address 0, see OutLds).
 #define LENS_OUT_SGPRS                                                                                                   \
     "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",      \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",      \
@@ -556,10 +547,10 @@ __device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], c
     "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 #define LENS_OUT_COMMON_OUT                                                                                              \
     [soff] "+&s"(soff), [nch] "+&s"(nch), [t] "=&v"(t), [t2] "=&v"(t2), [sc] "=&s"(sc), [so] "=&s"(so)
-#define LENS_OUT_COMMON_IN [ev] "s"(ev), [lane] "v"(lane_addr), [third] "v"(third), [thr] "v"(thr)
+#define LENS_OUT_COMMON_IN [ev] "s"(ev), [lane] "v"(lane_addr), [thr] "v"(thr)
 template <int PPL>
-__device__ __forceinline__ void output_loop_asm(const uint32_t *ev, uint32_t nch, uint32_t lane_addr, uint32_t third,
-                                                float (&v)[PPL], float (&cnt)[PPL])
+__device__ __forceinline__ void output_loop_asm(const uint32_t *ev, uint32_t nch, uint32_t lane_addr, float (&v)[PPL],
+                                                float (&cnt)[PPL])
 {
     static_assert(PPL >= 1 && PPL <= 4, "generated for one to four places per lane");
     uint32_t soff = 0, sc, so;
@@ -584,7 +575,7 @@ __device__ __forceinline__ void output_loop_asm(const uint32_t *ev, uint32_t nch
             : [v0] "+&v"(v[0]), [v1] "+&v"(v[1]), [v2] "+&v"(v[2]), [c0] "+&v"(cnt[0]), [c1] "+&v"(cnt[1]), [c2] "+&v"(cnt[2]),
               [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), LENS_OUT_COMMON_OUT
             : LENS_OUT_COMMON_IN
-            : "memory", "vcc", "scc", LENS_OUT_SGPRS, LENS_OUT_V64_79, LENS_OUT_V80_95, LENS_OUT_V96_111);
+            : "memory", "vcc", "scc", "m0", LENS_OUT_SGPRS, LENS_OUT_V64_79, LENS_OUT_V80_95, LENS_OUT_V96_111);
     } else {
         asm volatile(
 #include "output_loop_p4.inc"
@@ -617,18 +608,28 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
     // Queries of the group are handed to the wavefronts first come, first served: stream lengths vary by +-20 %
     // (std) between queries, and with a fixed assignment the slowest of the 16 wavefronts sets the pace (+14 %
     // on average, +26 % for the slowest workgroup at P=1000).
-    __shared__ int s_next;
-    __shared__ uint16_t s_order[OUT_ORDER_MAX];   // longest stream first (when the group is small enough to rank)
-    __shared__ uint32_t s_len[OUT_ORDER_MAX];
+    // The kernel owns no static LDS: the tile starts at LDS address 0 (the assembly loop of the 192-place tile relies
+    // on it, launch_output checks it) and the bookkeeping sits behind the tile in the same dynamic block.
+    unsigned char *book = smem + (W_LDS ? (size_t)a.F * PT * 4 : 0);
+    uint32_t *s_len = reinterpret_cast<uint32_t *>(book);                              // [OUT_ORDER_MAX]
+    uint16_t *s_order = reinterpret_cast<uint16_t *>(book + OUT_ORDER_MAX * 4);          // longest stream first (when the group is small enough to rank)
+    int &s_next = *reinterpret_cast<int *>(book + OUT_ORDER_MAX * 6);
     if (threadIdx.x == 0) s_next = 0;
     if constexpr (W_LDS) {
         float4 *dst = reinterpret_cast<float4 *>(smem);
         const int n4 = a.F * (PT / 4);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) {
             const int f = i / (PT / 4), c = i - f * (PT / 4);
-            // a 192-place tile may reach past the padded row (ldw is a multiple of 256, not of 192)
-            if (PPL != 3 || p0 + c * 4 < a.ldw) dst[i] = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
-            else dst[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (PPL == 3) {
+                // a 192-place tile may reach past the padded row (ldw is a multiple of 256, not of 192)
+                float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (p0 + c * 4 < a.ldw) x = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
+                // places 0..127 of the row -> pairs plane (behind the F x 256 bytes of the thirds plane), 128..191 -> thirds
+                unsigned char *d = c < 32 ? smem + (size_t)a.F * 256 + (size_t)f * 512 + c * 16 : smem + (size_t)f * 256 + (c - 32) * 16;
+                *reinterpret_cast<float4 *>(d) = x;
+            } else {
+                dst[i] = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
+            }
         }
     }
     const int qs = (int)(((long long)grp * a.Q) / a.n_groups);
@@ -667,7 +668,6 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         for (int k = 0; k < PPL; ++k) v[k] = (place[k] < a.P) ? a.vout[(size_t)grp * a.ldv + place[k]] : 0.0f;
     }
     const uint32_t lane_off = (uint32_t)lane * (PPL == 3 ? 8 : PPL * 4);
-    const uint32_t third_off = 512u - (uint32_t)lane * 4u;
     for (int it = 0;; ++it) {
         int q = qs + it;                       // carry: the one wavefront walks the group in order
         if (!a.carry) {
@@ -690,8 +690,8 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         if constexpr (W_LDS) {
             if (nch > 0) {
                 using lds_ptr = __attribute__((address_space(3))) unsigned char *;
-                const uint32_t lane_addr = (uint32_t)(uintptr_t)(lds_ptr)smem + lane_off;
-                output_loop_asm<PPL>(ev, (uint32_t)nch, lane_addr, 0u - (uint32_t)lane * 4u, v, cnt);
+                const uint32_t lane_addr = (uint32_t)(uintptr_t)(lds_ptr)smem + lane_off + (PPL == 3 ? (uint32_t)a.F * 256u : 0u);
+                output_loop_asm<PPL>(ev, (uint32_t)nch, lane_addr, v, cnt);
             }
         } else {
             // One chunk (EV_CHUNK events) per scalar prefetch, two SGPR buffers in ping-pong.  Per chunk: weight
@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
             for (int i = 0; i < EV_WORDS; ++i) ea[i] = ev[i];
             const char *p = reinterpret_cast<const char *>(ev);   // chunk being integrated (byte pointer: the token adds unshifted)
             for (int c = 0; c < nch; c += 2) {
-                load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, third_off, w);
+                load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, w);
                 p += EV_WORDS * 4;
                 const uint32_t *nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
                 if (c + 1 < nch) {
@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
                 if (ea[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(ea, w, v, cnt, acc);
                 else integrate_chunk<PPL, true>(ea, w, v, cnt, acc);
                 if (c + 1 >= nch) break;
-                load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, third_off, w);
+                load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
                 p += EV_WORDS * 4;
                 nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
                 if (c + 2 < nch) {
@@ -1384,8 +1384,19 @@ int dispatch_feature_f(const FeatArgs &a, hipStream_t st)
 template <int PPL, bool W_LDS>
 int launch_output(const OutArgs &a, int threads, hipStream_t st)
 {
-    const size_t lds = W_LDS ? (size_t)a.F * 64 * PPL * 4 : 0;
+    const size_t lds = (W_LDS ? (size_t)a.F * 64 * PPL * 4 : 0) + OUT_BOOK_BYTES;
     auto k = k_output_counts<PPL, W_LDS>;
+    if constexpr (PPL == 3) {
+        // The assembly loop reads the third places relative to LDS address 0: the kernel must not own static LDS
+        // (a __shared__ variable added to it would shift the dynamic block and silently break the addressing).
+        static int lds_base_checked = 0;
+        if (!lds_base_checked) {
+            hipFuncAttributes at;
+            if (hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k))) return (int)e;
+            if (at.sharedSizeBytes != 0) return LENS_ERR_UNSUPPORTED;
+            lds_base_checked = 1;
+        }
+    }
     if (int e = set_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)(a.ntiles * a.n_groups)), dim3(threads), lds, st, a);
     return (int)hipGetLastError();
@@ -1512,6 +1523,7 @@ static int output_ppl(int F, int P)
 int lens_event_scale(int F, int P)
 {
     const int ppl = output_ppl(F, P);
+    if (ppl == 3) return 512;   // the 128 places read as pairs; the 64 third places sit in a plane of half that stride
     return ppl ? 64 * ppl * 4 : 1;
 }
 

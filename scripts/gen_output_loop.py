@@ -21,11 +21,11 @@ bit-identical.
 
 Operands: [v0..] membranes, [c0..] spike counters (in/out), [soff] byte offset of the current chunk (in/out,
 starts at 0), [nch] chunks left (in/out, >= 1), [ev] stream pointer, [lane] LDS byte address of this lane's first
-weights in row 0, [third] (three places) minus four times the lane number, [thr] 1 - 2^-24 (a VGPR: a compare
-with an SGPR operand measured 3 % slower);
+weights in row 0 (three places: of its pair of places; the third place's plane starts at LDS address 0),
+[thr] 1 - 2^-24 (a VGPR: a compare with an SGPR operand measured 3 % slower);
 temporaries [a0..] accumulator, [t], [t2], [sc], [so] scalars.
 Clobbers: s[36:99] (the two chunk buffers), the weights' VGPRs (v64.. upwards: 16, 32 or 64 registers; three
-places: v[64:95] and v[96:111]), vcc, scc.
+places: v[64:95] and v[96:111], and m0), vcc, scc.
 """
 import os
 
@@ -52,7 +52,7 @@ def gen(ppl):
             regs.append(f"v{WTHIRD + i}")
         return regs
 
-    def read(i, ad, ad2):
+    def read(i, ad):
         w = W(i)
         if ppl == 1:
             return [f"ds_read_b32 {w[0]}, {ad}"]
@@ -60,7 +60,7 @@ def gen(ppl):
             return [f"ds_read_b128 v[{WPAIR + 4 * i}:{WPAIR + 4 * i + 3}], {ad}"]
         r = [f"ds_read_b64 v[{WPAIR + 2 * i}:{WPAIR + 2 * i + 1}], {ad}"]
         if ppl == 3:
-            r.append(f"ds_read_b32 {w[2]}, {ad2} offset:512")
+            r.append(f"ds_read_addtid_b32 {w[2]}")
         return r
 
     def fire_max():      # [t] = largest membrane of the lane's places (one place: the compare reads it directly)
@@ -89,14 +89,15 @@ def gen(ppl):
             ev = list(range(i0, min(EV_CHUNK, i0 + READ_GROUP)))
             for i in ev:
                 e(f"v_add_u32 {W(i)[0]}, {'%[so]' if i == 0 else off(i)}, %[lane]")
-            if ppl == 3:
-                for i in ev:
-                    e(f"v_add_u32 {W(i)[2]}, {W(i)[0]}, %[third]")
-            lines = [read(i, W(i)[0], W(i)[2] if ppl == 3 else None) for i in ev]
-            for k in range(max(len(l) for l in lines)):
-                for l in lines:
-                    if k < len(l):
-                        e(l[k])
+            for i in ev:
+                if ppl == 3:
+                    # The third place's weights sit in a plane of their own at LDS address 0, rows of 256 bytes = half
+                    # the row stride the event word is scaled by, and are read by M0 + 4 * lane: a scalar shift in
+                    # place of a second vector address.  (A write of M0 needs one other instruction before the read
+                    # that uses it: the 8-byte read.)  Microbenchmark of the whole mix: -5 %.
+                    e(f"s_lshr_b32 m0, {'%[so]' if i == 0 else off(i)}, 1")
+                for ln in read(i, W(i)[0]):
+                    e(ln)
         e("s_add_u32 %[soff], %[soff], 0x80")
         e("s_sub_u32 %[nch], %[nch], 1")
         e("s_cmp_eq_u32 %[nch], 0")

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(1024) name(unsigned long long *out, float seed
     unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
     for (int i = 0; i < ITER; ++i) {                                                              \
         asm volatile(body : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(addr), "+v"(w), "+s"(s0), [b2] "+v"(b2), [w3] "+v"(w3), [c3] "+v"(c3), [v3] "+v"(v3), [w96] "+v"(w96) \
-                     : "v"(lane8), "v"(cntv), "s"(smul), "v"(offs), [accp] "v"(accp), [accp4] "v"(accp4), [lane12] "v"(lane12), [lane4] "v"(lane4), [wp] "v"(wp), [half] "v"(half), [two] "v"(two), [mone] "v"(mone) : "scc", "vcc", "s20", "s21"); \
+                     : "v"(lane8), "v"(cntv), "s"(smul), "v"(offs), [accp] "v"(accp), [accp4] "v"(accp4), [lane12] "v"(lane12), [lane4] "v"(lane4), [wp] "v"(wp), [half] "v"(half), [two] "v"(two), [mone] "v"(mone) : "scc", "vcc", "s20", "s21", "m0"); \
     }                                                                                             \
     unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
     if (threadIdx.x % 64 == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;       \
@@ -190,6 +190,21 @@ KERNEL4(k_mix16p3c, "s_lshl_b32 s20, %6, 9\n" P3C_RD16 "s_waitcnt lgkmcnt(0)\n" 
 #define P3V_RD16 P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD P3V_RD
 KERNEL4(k_mix16p3v, "s_lshl_b32 s20, %6, 9\n" P3V_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
 
+// three places per lane, the third read addressed by M0 + lane (ds_read_addtid_b32) instead of a second VGPR address
+#define P3T_RD "s_lshr_b32 m0, s20, 1\n ds_read_b64 %5, %4\n ds_read_addtid_b32 %[w3]\n"
+#define P3T_AD "v_add_u32 %4, s20, %7\n"
+#define P3T_RD16 P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD
+KERNEL4(k_mix16p3t, "s_lshl_b32 s20, %6, 9\n" P3T_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+// the shipped order for comparison: all address adds first, then the reads
+#define P3S_AD "v_add_u32 %4, s20, %7\n v_add_u32 %[b2], %4, %10\n"
+#define P3S_RD "ds_read_b64 %5, %4\n ds_read_b32 %[w3], %[b2]\n"
+#define P3S_RD16 P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_AD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD P3S_RD
+KERNEL4(k_mix16p3s, "s_lshl_b32 s20, %6, 9\n" P3S_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+// two places per lane, both reads by M0 + lane
+#define T2_RD "s_mov_b32 m0, s20\n s_nop 0\n ds_read_addtid_b32 %2\n ds_read_addtid_b32 %3 offset:256\n"
+#define T2_RD16 T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD
+KERNEL4(k_mix16t2, "s_lshl_b32 s20, %6, 9\n" T2_RD16 "s_waitcnt lgkmcnt(0)\n" MIX_EVS "s_branch 90f\n" MIX_STEPN(1) MIX_STEPN(2) MIX_STEPN(3) MIX_STEPN(4) "90:\n")
+
 template <typename K>
 void run(const char *name, K kern) {
     unsigned long long *d; hipMalloc(&d, 512 * 16 * 8);
@@ -219,7 +234,7 @@ int main(int argc, char **argv) {
     RUN("valu3+s", k_v3s) RUN("valu3+sb", k_v3sb) RUN("ppl4", k_p4)
     RUN("ev_s2", k_s2) RUN("ev_pk", k_pk) RUN("iaf_s", k_iafs) RUN("iaf_p", k_iafp)
     RUN("mix16", k_mix16)   // "events" in its printout are whole 16-event chunks / 8
-    RUN("mix16p3", k_mix16p3) RUN("mix16p3v", k_mix16p3v) RUN("mix16p3b", k_mix16p3b) RUN("mix16p3c", k_mix16p3c) RUN("mix16n", k_mix16n)
+    RUN("mix16p3", k_mix16p3) RUN("mix16p3s", k_mix16p3s) RUN("mix16p3t", k_mix16p3t) RUN("mix16t2", k_mix16t2) RUN("mix16p3v", k_mix16p3v) RUN("mix16p3b", k_mix16p3b) RUN("mix16p3c", k_mix16p3c) RUN("mix16n", k_mix16n)
     RUN("mix16z", k_mix16z) RUN("mix16v", k_mix16v) RUN("mix16zv", k_mix16zv)
     RUN("mix16pre", k_mix16pre) RUN("mix16nolds", k_mix16nolds) RUN("mix16nostep", k_mix16nostep) RUN("mix16inl", k_mix16inl)
     RUN("add2", k_a2) RUN("add2+nt", k_nt) RUN("add2+tk", k_tk) RUN("add2+tk2", k_tk2) RUN("add2+call", k_call)

@@ -48,7 +48,7 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     assert L.lens_event_capacity_words(3, 0) == 32
     # tile width by (F, P): 256 places while they fit (F <= 156), else 192 or 128 -- whichever pads P less, times its rate
     assert L.lens_event_scale(63, 1000) == 1024 and L.lens_event_scale(5000, 1000) == 1
-    assert L.lens_event_scale(200, 100000) == 768 and L.lens_event_scale(200, 1000) == 512
+    assert L.lens_event_scale(200, 100000) == 512 and L.lens_event_scale(200, 1000) == 512
     assert L.lens_event_scale(200, 64) == 256 and L.lens_event_scale(300, 100000) == 512
 
 

@@ -195,6 +195,13 @@ KERNEL4(k_mix16p3v, "s_lshl_b32 s20, %6, 9\n" P3V_RD16 "s_waitcnt lgkmcnt(0)\n" 
 #define P3T_AD "v_add_u32 %4, s20, %7\n"
 #define P3T_RD16 P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD
 KERNEL4(k_mix16p3t, "s_lshl_b32 s20, %6, 9\n" P3T_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+// ... and the pair addresses of two events by one 64-bit add from an SGPR pair (needs the offsets of a chunk adjacent in the stream)
+#define P3U_AD "v_lshl_add_u64 %5, s[20:21], 0, %[accp]\n"
+#define P3U_RD16 P3U_AD P3U_AD P3U_AD P3U_AD P3U_AD P3U_AD P3U_AD P3U_AD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD
+KERNEL4(k_mix16p3u, "s_lshl_b32 s20, %6, 9\n s_mov_b32 s21, s20\n" P3U_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+// ... and with no address add at all (lower bound of what the address computation costs)
+#define P3N_RD16 P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD P3T_RD
+KERNEL4(k_mix16p3n, "s_lshl_b32 s20, %6, 9\n" P3N_RD16 "s_waitcnt lgkmcnt(0)\n" P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
 // the shipped order for comparison: all address adds first, then the reads
 #define P3S_AD "v_add_u32 %4, s20, %7\n v_add_u32 %[b2], %4, %10\n"
 #define P3S_RD "ds_read_b64 %5, %4\n ds_read_b32 %[w3], %[b2]\n"
@@ -234,7 +241,7 @@ int main(int argc, char **argv) {
     RUN("valu3+s", k_v3s) RUN("valu3+sb", k_v3sb) RUN("ppl4", k_p4)
     RUN("ev_s2", k_s2) RUN("ev_pk", k_pk) RUN("iaf_s", k_iafs) RUN("iaf_p", k_iafp)
     RUN("mix16", k_mix16)   // "events" in its printout are whole 16-event chunks / 8
-    RUN("mix16p3", k_mix16p3) RUN("mix16p3s", k_mix16p3s) RUN("mix16p3t", k_mix16p3t) RUN("mix16t2", k_mix16t2) RUN("mix16p3v", k_mix16p3v) RUN("mix16p3b", k_mix16p3b) RUN("mix16p3c", k_mix16p3c) RUN("mix16n", k_mix16n)
+    RUN("mix16p3", k_mix16p3) RUN("mix16p3s", k_mix16p3s) RUN("mix16p3t", k_mix16p3t) RUN("mix16p3u", k_mix16p3u) RUN("mix16p3n", k_mix16p3n) RUN("mix16t2", k_mix16t2) RUN("mix16p3v", k_mix16p3v) RUN("mix16p3b", k_mix16p3b) RUN("mix16p3c", k_mix16p3c) RUN("mix16n", k_mix16n)
     RUN("mix16z", k_mix16z) RUN("mix16v", k_mix16v) RUN("mix16zv", k_mix16zv)
     RUN("mix16pre", k_mix16pre) RUN("mix16nolds", k_mix16nolds) RUN("mix16nostep", k_mix16nostep) RUN("mix16inl", k_mix16inl)
     RUN("add2", k_a2) RUN("add2+nt", k_nt) RUN("add2+tk", k_tk) RUN("add2+tk2", k_tk2) RUN("add2+call", k_call)

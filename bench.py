@@ -252,10 +252,13 @@ def main():
     shared = os.environ.get("LENS_BENCH_SHARED_DEVICE") == "1"
     if shared:
         local = 0
+    # Test hook: LENS_BENCH_GROUP_OF_ONE=1 makes a single rank form a process group of its own over RCCL and run the
+    # multi-GPU code (collectives on device tensors, DB-sharded step with its all-gather and merge) on a one-GPU box.
+    grouped = world > 1 or os.environ.get("LENS_BENCH_GROUP_OF_ONE") == "1"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if shared:
@@ -270,7 +273,7 @@ def main():
     shard = a.shard
     if shard == "auto":
         shard = "db" if (world > 1 and a.places // world >= 8192) else "queries"
-    if world == 1:
+    if not grouped:
         shard = "queries"
 
     w1, w2p = pretrained()
@@ -321,7 +324,7 @@ def main():
         for _ in range(max(2, a.warmup)):
             pipe.submit(frames, SEQ_L, TOPK)
         pipe.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -333,11 +336,11 @@ def main():
             pipe.submit(frames, SEQ_L, TOPK)
     torch.cuda.synchronize()
     my_elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     multi = None
-    if world > 1:
+    if grouped:
         cpu = shared                                                 # gloo: CPU tensors only
         tdev = "cpu" if cpu else dev
         tt = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
@@ -412,7 +415,7 @@ def main():
                                    + (f" sharded over {world} GPUs" if shard == "db" else "")
                                    + f", {total_queries} queries per step, state reset per query, T={T_STEPS}, "
                                    f"L={SEQ_L}, top-{TOPK}",
-                       "places": a.places, "queries_per_step": total_queries, "shard": shard if world > 1 else "none",
+                       "places": a.places, "queries_per_step": total_queries, "shard": shard if grouped else "none",
                        "streams": a.streams, "feature_spike_words_per_query": words},
             "kernels_ms": dict(zip(names, avg_ms)),
             "roofline": roof,
@@ -444,7 +447,7 @@ def main():
             line["cpu_baseline"] = base
             line["parity"] = parity
         print(json.dumps(line))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,7 +1,8 @@
 """The complete sharded path (ShardedMatcher / ShardedStep: HIP kernels per shard -> all-gather of top-K -> merge
 kernel) with two ranks.  On a one-GPU box both ranks use cuda:0 and the collective travels over gloo (host
 staging); where torch.cuda.device_count() >= 2 the `rccl` cases run the same code one rank per GPU over RCCL
-(backend "nccl") and are skipped otherwise."""
+(backend "nccl") and are skipped otherwise.  A group of ONE rank over RCCL runs everywhere: it takes the device-tensor
+collective path that the multi-GPU runs take."""
 import os
 import socket
 
@@ -81,6 +82,19 @@ def test_two_rank_sharded_matcher_equals_single_device(backend):
     assert ret.get(timeout=5) == 1
 
 
+def test_single_rank_group_over_rccl():
+    """The device-tensor collective path (no host staging) through RCCL itself, on one GPU: a process group of one
+    rank with backend "nccl".  The all-gather of the packed top-K block, the all-reduce and the ordering of the side
+    stream against the kernels' stream are the calls a multi-GPU run makes; only the peers are missing."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), 1500, 24, ret, "nccl"))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1
+
+
 @pytest.mark.parametrize("backend", ["gloo", pytest.param("nccl", marks=needs_two_gpus)])
 @pytest.mark.parametrize("shard", ["queries", "db"])
 def test_bench_two_ranks_the_way_the_driver_launches_it(shard, backend):
@@ -112,3 +126,24 @@ def test_bench_two_ranks_the_way_the_driver_launches_it(shard, backend):
     if shard == "db":
         assert d["multi_gpu"]["gather_merge_ms"] > 0
         assert d["parity"]["mismatches"] == 0 and d["parity"]["top25_idx_identical"]
+
+
+def test_bench_db_sharded_step_over_rccl_with_one_rank():
+    """bench.py's DB-sharded mode under torch.distributed.run with ONE rank that forms an RCCL group of its own
+    (test hook LENS_BENCH_GROUP_OF_ONE=1): barriers, the all-reduce / all-gather of the timings on device tensors and
+    the overlapped top-K all-gather + merge all go through RCCL, which the two-rank cases cannot on a one-GPU box."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LENS_BENCH_GROUP_OF_ONE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--queries", "256", "--places", "20000", "--shard", "db", "--no-extras"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["shard"] == "db"
+    assert d["multi_gpu"]["backend"] == "nccl" and d["multi_gpu"]["ranks_seen"] == [0]
+    assert d["multi_gpu"]["gather_merge_ms"] > 0
+    assert d["parity"]["mismatches"] == 0 and d["parity"]["top25_idx_identical"]

@@ -532,8 +532,10 @@ __device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], c
 
 // The chunk loop of one query in gfx950 assembly (scripts/gen_output_loop.py), for the LDS tiles: same f32 operations in
 // the same order as integrate_chunk, laid out as two chains of code that C++ cannot express without flag bookkeeping.
-// `lane_addr` = LDS byte address of this lane's first weights in row 0 of the tile (three places per lane: of its
-// pair of places; the third place is read through M0 from the plane at LDS address 0, see OutLds).
+// `nwords` = address of the stream's length in words (loaded together with the first chunk: whole chunks are
+// readable from any stream, the workspace holds the worst case), `lane_addr` = LDS byte address of this lane's first
+// weights in row 0 of the tile (three places per lane: of its pair of places; the third place is read through M0 from
+// the plane at LDS address 0, see lane_place).
 #define LENS_OUT_SGPRS                                                                                                   \
     "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",      \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",      \
@@ -546,14 +548,14 @@ __device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], c
 #define LENS_OUT_V112_127                                                                                                \
     "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 #define LENS_OUT_COMMON_OUT                                                                                              \
-    [soff] "+&s"(soff), [nch] "+&s"(nch), [t] "=&v"(t), [t2] "=&v"(t2), [sc] "=&s"(sc), [so] "=&s"(so)
-#define LENS_OUT_COMMON_IN [ev] "s"(ev), [lane] "v"(lane_addr), [thr] "v"(thr)
+    [soff] "+&s"(soff), [nch] "=&s"(nch), [t] "=&v"(t), [t2] "=&v"(t2), [sc] "=&s"(sc), [so] "=&s"(so)
+#define LENS_OUT_COMMON_IN [ev] "s"(ev), [nwp] "s"(nwords), [lane] "v"(lane_addr), [thr] "v"(thr)
 template <int PPL>
-__device__ __forceinline__ void output_loop_asm(const uint32_t *ev, uint32_t nch, uint32_t lane_addr, float (&v)[PPL],
-                                                float (&cnt)[PPL])
+__device__ __forceinline__ void output_loop_asm(const uint32_t *ev, const uint32_t *nwords, uint32_t lane_addr,
+                                                float (&v)[PPL], float (&cnt)[PPL])
 {
     static_assert(PPL >= 1 && PPL <= 4, "generated for one to four places per lane");
-    uint32_t soff = 0, sc, so;
+    uint32_t soff = 0, nch, sc, so;
     float a[PPL], t, t2;
     const float thr = 0.99999994f;   // 1 - 2^-24: the clip rounds it up to exactly 1.0
     if constexpr (PPL == 1) {
@@ -686,14 +688,12 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
             acc[k] = 0.0f;
         }
         const uint32_t *ev = a.events + (size_t)q * a.cap;
-        const int nch = __builtin_amdgcn_readfirstlane((int)(a.nwords[q] / EV_WORDS));
         if constexpr (W_LDS) {
-            if (nch > 0) {
-                using lds_ptr = __attribute__((address_space(3))) unsigned char *;
-                const uint32_t lane_addr = (uint32_t)(uintptr_t)(lds_ptr)smem + lane_off + (PPL == 3 ? (uint32_t)a.F * 256u : 0u);
-                output_loop_asm<PPL>(ev, (uint32_t)nch, lane_addr, v, cnt);
-            }
+            using lds_ptr = __attribute__((address_space(3))) unsigned char *;
+            const uint32_t lane_addr = (uint32_t)(uintptr_t)(lds_ptr)smem + lane_off + (PPL == 3 ? (uint32_t)a.F * 256u : 0u);
+            output_loop_asm<PPL>(ev, a.nwords + q, lane_addr, v, cnt);
         } else {
+            const int nch = __builtin_amdgcn_readfirstlane((int)(a.nwords[q] / EV_WORDS));
             // One chunk (EV_CHUNK events) per scalar prefetch, two SGPR buffers in ping-pong.  Per chunk: weight
             // reads -> lgkmcnt(0) -> scalar load of the next chunk -> VALU/SALU-only integration while it is in flight.
             uint32_t ea[EV_WORDS], eb[EV_WORDS];

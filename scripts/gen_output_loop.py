@@ -20,7 +20,7 @@ The arithmetic is the same sequence of f32 operations as the C++ path (integrate
 bit-identical.
 
 Operands: [v0..] membranes, [c0..] spike counters (in/out), [soff] byte offset of the current chunk (in/out,
-starts at 0), [nch] chunks left (in/out, >= 1), [ev] stream pointer, [lane] LDS byte address of this lane's first
+starts at 0), [nch] chunks left (out; loaded from [nwp], the address of the stream's length in words), [ev] stream pointer, [lane] LDS byte address of this lane's first
 weights in row 0 (three places: of its pair of places; the third place's plane starts at LDS address 0),
 [thr] 1 - 2^-24 (a VGPR: a compare with an SGPR operand measured 3 % slower);
 temporaries [a0..] accumulator, [t], [t2], [sc], [so] scalars.
@@ -251,9 +251,14 @@ def gen(ppl):
     e = hot.append
     for k in range(ppl):
         e(f"v_mov_b32 {A[k]}, 0")
+    # the stream's length travels with its first chunk: one memory latency per query instead of two in a row
+    e("s_load_dword %[nch], %[nwp], 0x0")
     e(f"s_load_dwordx16 s[{EA}:{EA + 15}], %[ev], %[soff] offset:0x0")
     e(f"s_load_dwordx16 s[{EA + 16}:{EA + 31}], %[ev], %[soff] offset:0x40")
     e("s_waitcnt lgkmcnt(0)")
+    e(f"s_lshr_b32 %[nch], %[nch], {EV_CHUNK.bit_length()}")     # words -> chunks of 2 * EV_CHUNK words
+    e("s_cmp_eq_u32 %[nch], 0")
+    e("s_cbranch_scc1 DONE_%=")
     e("LOOP_%=:")
     chunk(EA, EB, "a")
     e("s_cbranch_scc1 DONE_%=")

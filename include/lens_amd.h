@@ -194,7 +194,7 @@ int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Q
  * Training path (`python main.py --train_model`), the reference's training run (benchmark size: a 100 000-row output layer).
  * ------------------------------------------------------------------------------------------- */
 
-/* Padded fan-in the training kernel uses for n_in inputs (64/128/200/208/256/512/1024; 0 = n_in > 1024, unsupported).
+/* Padded fan-in the training kernel uses for n_in inputs (64/128/200/208/256/512/1024/2048; 0 = n_in > 2048, unsupported).
  * x_table / mpre_table rows must be zero padded to a leading dimension >= this value. */
 int lens_train_in_pad(int n_in);
 
@@ -221,7 +221,7 @@ int lens_layer_forward_clamped(const float *d_x, int S, int ldx, const float *d_
  *   d_order int32 [T]                                sample presented at each step
  *   d_force_idx int32 [T] or NULL                    int(labels / filter) per step (spike forcing = output layer)
  *   d_eta_ip, d_eta_stdp float [T]                   learning rates in effect at each step (annealing schedule)
- * n_in <= 1024 (the weight row of a neuron lives in the registers of 1, 2, 4 or 8 adjacent lanes).
+ * n_in <= 2048 (the weight row of a neuron lives in the registers of 1, 2, 4, 8 or 16 adjacent lanes).
  */
 int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, const uint8_t *d_inh, int ldm,
                      const float *d_fire_rate, int have_rate, const float *d_x_table, const float *d_mpre_table, int ldx,

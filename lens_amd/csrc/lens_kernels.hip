@@ -954,7 +954,7 @@ __global__ void __launch_bounds__(256) k_topk_merge(const int32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // f1. Training (`--train_model`): lens/train_model.py:157-177 + calc_stdp, lens/src/blitnet.py:183-254.
 //   Every output neuron of a layer evolves independently given the sample sequence (its forward value,
-//   STDP row, threshold and homeostasis only involve its own weight row), so 1, 2, 4 or 8 adjacent lanes own one
+//   STDP row, threshold and homeostasis only involve its own weight row), so 1, 2, 4, 8 or 16 adjacent lanes own one
 //   row, keep it in registers for all T steps, and the per-step input vector is staged through LDS.  Per-element sign
 //   masks are kept as packed bits.  IN_PAD: padded fan-in; x_table / mpre_table rows are zero padded to ldx >= IN_PAD.
 // ------------------------------------------------------------------------------------------
@@ -1137,7 +1137,7 @@ __device__ __forceinline__ void stdp_free_row(float (&w)[HP], const uint32_t (&e
     }
 }
 
-// LPR = lanes per weight row (1, 2, 4 or 8).  A row of more than 128 weights would not fit the 256 architectural
+// LPR = lanes per weight row (1, 2, 4, 8 or 16: at most one DPP row of lanes).  A row of more than 128 weights would not fit the 256 architectural
 // VGPRs of one lane, so LPR adjacent lanes share it: lane LPR*r + h holds columns [h*HP, (h+1)*HP) of row r.  The
 // forward chain runs over the first lane's columns, is handed to the next lane (DPP row_shr:1) and continues
 // there, and so on: still ONE ascending fmaf chain per row.  The last lane's result is then broadcast to the row's
@@ -1145,7 +1145,7 @@ __device__ __forceinline__ void stdp_free_row(float (&w)[HP], const uint32_t (&e
 template <int IN_PAD, int LPR, bool SPK>
 __device__ __forceinline__ void train_layer_body(const TrainArgs &a)
 {
-    static_assert(IN_PAD % (4 * LPR) == 0 && IN_PAD <= 1024 && (LPR == 1 || LPR == 2 || LPR == 4 || LPR == 8),
+    static_assert(IN_PAD % (4 * LPR) == 0 && IN_PAD <= 2048 && (LPR == 1 || LPR == 2 || LPR == 4 || LPR == 8 || LPR == 16),
                   "rows are staged in 256-element pieces and shared by a power-of-two group of lanes inside a DPP row");
     constexpr int HP = IN_PAD / LPR;              // columns per lane
     constexpr int NB = (HP + 31) / 32;
@@ -1264,7 +1264,7 @@ __device__ __forceinline__ void train_layer_body(const TrainArgs &a)
 LENS_TRAIN_KERNEL(64, 1, 5) LENS_TRAIN_KERNEL(128, 1, 3) LENS_TRAIN_KERNEL(128, 2, 5) LENS_TRAIN_KERNEL(200, 1, 2)
 LENS_TRAIN_KERNEL(200, 2, 3) LENS_TRAIN_KERNEL(208, 1, 2)
 LENS_TRAIN_KERNEL(208, 2, 3) LENS_TRAIN_KERNEL(208, 4, 5) LENS_TRAIN_KERNEL(256, 2, 3) LENS_TRAIN_KERNEL(256, 4, 5)
-LENS_TRAIN_KERNEL(512, 4, 3) LENS_TRAIN_KERNEL(512, 8, 5) LENS_TRAIN_KERNEL(1024, 8, 3)
+LENS_TRAIN_KERNEL(512, 4, 3) LENS_TRAIN_KERNEL(512, 8, 5) LENS_TRAIN_KERNEL(1024, 8, 3) LENS_TRAIN_KERNEL(2048, 16, 3)
 #undef LENS_TRAIN_KERNEL
 
 // y[s][o] = clamp(chain_n fmaf(x[s][n], w[o][n]) - thr[o], 0, 1)  (train_model.py:163-168)
@@ -1688,7 +1688,7 @@ int lens_topk_merge(const int32_t *d_idx_in, const float *d_val_in, int R, int Q
 
 int lens_train_in_pad(int n_in)
 {
-    for (int p : {64, 128, 200, 208, 256, 512, 1024})   // 200: the default LENS feature count (2 x 10 x 10), no padding
+    for (int p : {64, 128, 200, 208, 256, 512, 1024, 2048})   // 200: the default LENS feature count (2 x 10 x 10), no padding
         if (n_in <= p) return p;
     return 0;
 }
@@ -1722,7 +1722,8 @@ static int train_lanes_per_row(int pad, int n_out)
     case 208: lo = 1; hi = 4; break;
     case 256: lo = 2; hi = 4; break;
     case 512: lo = 4; hi = 8; break;
-    default: lo = 8; hi = 8; break;
+    case 1024: lo = 8; hi = 8; break;
+    default: lo = 16; hi = 16; break;
     }
     if (forced >= lo && forced <= hi && (forced & (forced - 1)) == 0) return forced;
     int best = lo;
@@ -1774,7 +1775,7 @@ int lens_train_layer(float *d_w, int ldw, float *d_thr, const uint8_t *d_exc, co
     LENS_TRAIN_CASE(64, 1) LENS_TRAIN_CASE(128, 1) LENS_TRAIN_CASE(128, 2) LENS_TRAIN_CASE(200, 1) LENS_TRAIN_CASE(200, 2)
     LENS_TRAIN_CASE(208, 1) LENS_TRAIN_CASE(208, 2)
     LENS_TRAIN_CASE(208, 4) LENS_TRAIN_CASE(256, 2) LENS_TRAIN_CASE(256, 4) LENS_TRAIN_CASE(512, 4) LENS_TRAIN_CASE(512, 8)
-    LENS_TRAIN_CASE(1024, 8)
+    LENS_TRAIN_CASE(1024, 8) LENS_TRAIN_CASE(2048, 16)
 #undef LENS_TRAIN_CASE
     return LENS_ERR_UNSUPPORTED;
 }

@@ -275,7 +275,7 @@ def topk_merge(idx_in, val_in, out=None):
 def train_in_pad(n_in):
     pad = int(_lib.lib().lens_train_in_pad(int(n_in)))
     if pad == 0:
-        raise _lib.LensAmdError(f"training kernel supports a fan-in of at most 1024 inputs, got {n_in}")
+        raise _lib.LensAmdError(f"training kernel supports a fan-in of at most 2048 inputs, got {n_in}")
     return pad
 
 

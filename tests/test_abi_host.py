@@ -290,14 +290,14 @@ def test_event_windows_skip_empty_windows(tmp_path):
 
 
 def test_training_pad_covers_wide_layers_and_short_csv_annealing():
-    """Fan-ins up to 1024 have a kernel instantiation (e.g. --dims 20 => 400 inputs, 800 features); the learning-rate
+    """Fan-ins up to 2048 have a kernel instantiation (e.g. --dims 20 => 400 inputs, 800 features); the learning-rate
     annealing horizon is reference_places * epochs (lens/train_model.py:124-125,143) even when fewer steps are taken."""
     import torch
     from lens_amd import _lib
     from lens_amd.train_model import anneal_schedule
     L = _lib.lib()
-    assert [L.lens_train_in_pad(n) for n in (1, 64, 65, 200, 201, 256, 257, 800, 1024, 1025)] == \
-        [64, 64, 128, 200, 208, 256, 512, 1024, 1024, 0]
+    assert [L.lens_train_in_pad(n) for n in (1, 64, 65, 200, 201, 256, 257, 800, 1024, 1025, 2048, 2049)] == \
+        [64, 64, 128, 200, 208, 256, 512, 1024, 1024, 2048, 2048, 0]
 
     class Layer:
         eta_ip = torch.tensor(0.02)

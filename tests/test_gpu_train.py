@@ -67,9 +67,10 @@ def test_training_kernels_match_oracle_on_random_layers():
     from oracle import oracle as O
     from lens_amd.engine import train_layer, train_in_pad, pad_table
     rng = np.random.default_rng(5)
-    # fan-in 300 / 800: weight rows shared by 4 / 8 lanes (512 / 1024 padded columns), e.g. --dims 20 feature layers
+    # fan-in 300 / 800 / 1500: weight rows shared by 4 / 8 / 16 lanes (512 / 1024 / 2048 padded columns), e.g. --dims 20 feature layers
     for n_out, n_in, spk in ((70, 33, False), (200, 100, False), (130, 200, True), (5, 256, True),
-                             (90, 300, False), (61, 400, True), (1000, 800, True), (1000, 800, False), (9, 1024, True)):
+                             (90, 300, False), (61, 400, True), (1000, 800, True), (1000, 800, False), (9, 1024, True),
+                             (70, 1500, True), (33, 2048, False)):
         S, T = 11, 60
         w0 = (rng.standard_normal((n_out, n_in)) * 0.6).astype(np.float32)
         w0[rng.random((n_out, n_in)) < 0.3] = 0

@@ -16,7 +16,7 @@ eng = LensEngine(w1, synthetic_database(w2p, P), bench.ROI, bench.DIMS, bench.T_
 fr = synthetic_frames(Q, bench.ROI, seed=1234).cuda()
 eng.forward_counts(fr, carry=False)
 out = torch.empty(Q, P, device="cuda")
-for g in [0, 4, 8, 12, 16, 24, 32, 64]:
+for g in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 4, 8, 12, 16, 24, 32, 64]):
     def run():
         _lib.check(_lib.lib().lens_output_counts(_ptr(eng.events), eng.cap, _ptr(eng.nwords), Q, _ptr(eng.w2t), eng.F, eng.P,
                                                   eng.ldw2, None, 0, g, 0, _ptr(out), P, _stream()), "lens_output_counts")

@@ -80,41 +80,49 @@ def gen(ppl):
         lab = lambda n: f"{n}{name}_%="
 
         # ---- weight reads, next chunk's prefetch ----
-        e(f"s_and_b32 %[so], {off(0)}, 0x7fffffff")
         # Every weight register first holds the address of its own read (a read may overwrite its address register:
         # the address is consumed when the read issues), so all addresses are computed before the first read is
         # issued and no read waits for the add right before it.  Same-box, against the address right before its
         # read: groups of two events -1.9 %, of four, eight or all sixteen -2.8 %.
-        for i0 in range(0, EV_CHUNK, READ_GROUP):
-            ev = list(range(i0, min(EV_CHUNK, i0 + READ_GROUP)))
-            for i in ev:
-                e(f"v_add_u32 {W(i)[0]}, {'%[so]' if i == 0 else off(i)}, %[lane]")
-            for i in ev:
-                if ppl == 3:
-                    # The third place's weights sit in a plane of their own at LDS address 0, rows of 256 bytes = half
-                    # the row stride the event word is scaled by, and are read by M0 + 4 * lane: a scalar shift in
-                    # place of a second vector address.  (A write of M0 needs one other instruction before the read
-                    # that uses it: the 8-byte read.)  Microbenchmark of the whole mix: -5 %.
-                    e(f"s_lshr_b32 m0, {'%[so]' if i == 0 else off(i)}, 1")
-                for ln in read(i, W(i)[0]):
-                    e(ln)
-        e("s_add_u32 %[soff], %[soff], 0x80")
-        e("s_sub_u32 %[nch], %[nch], 1")
-        e("s_cmp_eq_u32 %[nch], 0")
-        # LDS and scalar memory share one counter and scalar loads return out of order: the reads must have landed
-        # before the prefetch is issued, or waiting for them would wait for the prefetch as well
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"s_cbranch_scc1 {lab('NOPF')}")
-        e(f"s_load_dwordx16 s[{other}:{other + 15}], %[ev], %[soff] offset:0x0")
-        e(f"s_load_dwordx16 s[{other + 16}:{other + 31}], %[ev], %[soff] offset:0x40")
-        e(f"{lab('NOPF')}:")
+        def read_phase(e, off0):      # off0: register that holds the first event's offset without the EV_CHUNK_MIXED flag
+            for i0 in range(0, EV_CHUNK, READ_GROUP):
+                ev = list(range(i0, min(EV_CHUNK, i0 + READ_GROUP)))
+                for i in ev:
+                    e(f"v_add_u32 {W(i)[0]}, {off0 if i == 0 else off(i)}, %[lane]")
+                for i in ev:
+                    if ppl == 3:
+                        # The third place's weights sit in a plane of their own at LDS address 0, rows of 256 bytes = half
+                        # the row stride the event word is scaled by, and are read by M0 + 4 * lane: a scalar shift in
+                        # place of a second vector address.  (A write of M0 needs one other instruction before the read
+                        # that uses it: the 8-byte read.)  Microbenchmark of the whole mix: -5 %.
+                        e(f"s_lshr_b32 m0, {off0 if i == 0 else off(i)}, 1")
+                    for ln in read(i, W(i)[0]):
+                        e(ln)
+            e("s_add_u32 %[soff], %[soff], 0x80")
+            e("s_sub_u32 %[nch], %[nch], 1")          # borrow (scc) = no chunk follows; [nch] = chunks after the next one
+            # LDS and scalar memory share one counter and scalar loads return out of order: the reads must have landed
+            # before the prefetch is issued, or waiting for them would wait for the prefetch as well
+            e("s_waitcnt lgkmcnt(0)")
+
+        # The chunk's flag first: a chunk whose counts are all 1 (96 % at the benchmark's density) uses its first offset
+        # word as it is; the others get a copy of the read phase that masks the flag off, behind the loop.
         e(f"s_bitcmp1_b32 {off(0)}, 31")
         e(f"s_cbranch_scc1 {lab('MIXED')}")
+        read_phase(e, off(0))
+        e(f"s_cbranch_scc1 {lab('A0')}")
+        e(f"s_load_dwordx16 s[{other}:{other + 15}], %[ev], %[soff] offset:0x0")
+        e(f"s_load_dwordx16 s[{other + 16}:{other + 31}], %[ev], %[soff] offset:0x40")
         # A chunk with counts other than 1: is any of them 2^23 or more (mantissa LSB = data, not the EV_EMPTY_NEXT
         # flag)?  The OR of the 16 count words is below 0x4b000000 only if every count is (a few combinations of
         # counts from 2^21 up test positive as well and take the careful variant, which is correct for any chunk).
-        c = cold.append
+        c = warm.append
         c(f"{lab('MIXED')}:")
+        c(f"s_and_b32 %[so], {off(0)}, 0x7fffffff")
+        read_phase(c, "%[so]")
+        c(f"s_cbranch_scc1 {lab('NOPF')}")
+        c(f"s_load_dwordx16 s[{other}:{other + 15}], %[ev], %[soff] offset:0x0")
+        c(f"s_load_dwordx16 s[{other + 16}:{other + 31}], %[ev], %[soff] offset:0x40")
+        c(f"{lab('NOPF')}:")
         c(f"s_or_b32 %[sc], {cnt(0)}, {cnt(1)}")
         for i in range(2, EV_CHUNK):
             c(f"s_or_b32 %[sc], %[sc], {cnt(i)}")
@@ -160,7 +168,7 @@ def gen(ppl):
             else:
                 main(f"{lab('END')}:")
                 main("s_waitcnt lgkmcnt(0)")          # the next chunk's words
-                main("s_cmp_eq_u32 %[nch], 0")
+                main("s_cmp_eq_u32 %[nch], -1")          # wrapped around: that was the last chunk
             e = warm.append
 
             # ---- chain S ----
@@ -259,6 +267,7 @@ def gen(ppl):
     e(f"s_lshr_b32 %[nch], %[nch], {EV_CHUNK.bit_length()}")     # words -> chunks of 2 * EV_CHUNK words
     e("s_cmp_eq_u32 %[nch], 0")
     e("s_cbranch_scc1 DONE_%=")
+    e("s_sub_u32 %[nch], %[nch], 1")                 # chunks after the first
     e("LOOP_%=:")
     chunk(EA, EB, "a")
     e("s_cbranch_scc1 DONE_%=")

@@ -60,18 +60,16 @@ def gen():
     def issue_input(i, regs):
         """LDS reads of the next active input of group i into `regs` (and clear its mask bit)"""
         e(f"s_ff1_i32_b64 s{S_N}, {pair(M_IN[i])}")
-        e(f"s_lshl_b32 s{S_TMP}, s{S_N}, 10")
-        e(f"v_add_u32 v{ADDR}, s{S_TMP}, %[wa{i}]")
+        e(f"v_lshl_add_u32 v{ADDR}, s{S_N}, 10, %[wa{i}]")      # row n of W1T: 256 floats
         e(f"ds_read2st64_b32 v[{regs[0]}:{regs[1]}], v{ADDR} offset1:1")
         e(f"ds_read2st64_b32 v[{regs[2]}:{regs[3]}], v{ADDR} offset0:2 offset1:3")
         e(f"s_bitset0_b64 {pair(M_IN[i])}, s{S_N}")
 
     def add_input(regs, outstanding):
         """acc += regs, in order; `outstanding` = LDS reads issued after these"""
-        e(f"s_waitcnt lgkmcnt({outstanding + 1})")
+        e(f"s_waitcnt lgkmcnt({outstanding})")
         e(f"v_add_f32 v{ACC[0]}, v{ACC[0]}, v{regs[0]}")
         e(f"v_add_f32 v{ACC[1]}, v{ACC[1]}, v{regs[1]}")
-        e(f"s_waitcnt lgkmcnt({outstanding})")
         e(f"v_add_f32 v{ACC[2]}, v{ACC[2]}, v{regs[2]}")
         e(f"v_add_f32 v{ACC[3]}, v{ACC[3]}, v{regs[3]}")
 

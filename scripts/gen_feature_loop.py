@@ -43,6 +43,7 @@ def gen():
     out = []
     e = out.append
     sfx = [""]
+    ool = {}                                    # out-of-line blocks of a step copy, emitted behind the loop
 
     def L(n): return f"{n}{sfx[0]}_%="          # label local to one copy of the step body
     def G(n): return f"{n}_%="                  # shared label
@@ -89,10 +90,31 @@ def gen():
         e(f"s_or_b64 {pair(S_PAIR)}, {pair(S_PAIR)}, {pair(S_HOT)}")
         e(f"s_cmp_eq_u64 {pair(S_PAIR)}, 0")
         e(f"s_cbranch_scc1 {L('EMPTY')}")
+        # The step's first active input is read straight into the accumulator (fl(0 + w) is w; a -0 weight leaves +0
+        # instead of -0 there, which v + acc cannot see: a clipped v is never -0, and a carried-in -0 with no other
+        # input ends as clip(+-0) = +0 either way): no zeroing and no adds for it.  Out of line: the first input in the
+        # upper group (none in the lower), and a step with no input at all (a membrane at exactly 1.0 brought it here).
+        e(f"s_cmp_eq_u64 {pair(M_IN[0])}, 0")
+        e(f"s_cbranch_scc1 {L('FIRST1')}")
+        issue_input(0, ACC)
+        o = ool.setdefault(name, []).append
+        o(f"{L('FIRST1')}:")
+        o(f"s_cmp_eq_u64 {pair(M_IN[1])}, 0")
+        o(f"s_cbranch_scc1 {L('ZERO')}")
+        lines_before = len(out)                                 # issue_input emits into the main stream: move its lines
+        issue_input(1, ACC)
+        moved = out[lines_before:]
+        del out[lines_before:]
+        for ln in moved:
+            o(ln)
+        o(f"s_branch {L('GRP1')}")
+        o(f"{L('ZERO')}:")
         for j in range(4):
-            e(f"v_mov_b32 v{ACC[j]}, 0")
+            o(f"v_mov_b32 v{ACC[j]}, 0")
+        o(f"s_branch {L('IN_DONE1')}")
         # active inputs in ascending n; the reads of the next input are in flight while the current one is added
         for i in range(2):
+            e(f"{L(f'GRP{i}')}:")
             e(f"s_cmp_eq_u64 {pair(M_IN[i])}, 0")
             e(f"s_cbranch_scc1 {L(f'IN_DONE{i}')}")
             issue_input(i, W)
@@ -113,6 +135,7 @@ def gen():
             add_input(W2, 0)
             e(f"{L(f'IN_DONE{i}')}:")
         # vm = v + I
+        e("s_waitcnt lgkmcnt(0)")                               # a single input: its reads went to the accumulator
         for j in range(4):
             e(f"v_add_f32 v{ACC[j]}, {V[j]}, v{ACC[j]}")
         e(f"v_max3_f32 v{TMP}, v{ACC[0]}, v{ACC[1]}, v{ACC[2]}")
@@ -219,6 +242,8 @@ def gen():
     def multi(name):
         """rare: some count exceeds 1 -> mark the chunks, remember the last event's count word"""
         sfx[0] = name
+        for ln in ool.get(name, []):
+            e(ln)
         e(f"{L('MULTI')}:")
         e(f"s_mov_b32 s{S_BASE}, %[count]")
         e(f"v_bfrev_b32 v{D1}, 1")

@@ -85,11 +85,9 @@ def gen():
         e(f"v_cmp_ge_u32_e64 {pair(M_IN[0])}, %[px0], v{cur[0]}")
         e(f"v_cmp_ge_u32_e64 {pair(M_IN[1])}, %[px1], v{cur[1]}")
         e(f"v_add_u32 %[caddr], 0x80, %[caddr]")
-        # quiet step?  no input spike, no membrane at exactly 1.0
-        e(f"s_or_b64 {pair(S_PAIR)}, {pair(M_IN[0])}, {pair(M_IN[1])}")
-        e(f"s_or_b64 {pair(S_PAIR)}, {pair(S_PAIR)}, {pair(S_HOT)}")
-        e(f"s_cmp_eq_u64 {pair(S_PAIR)}, 0")
-        e(f"s_cbranch_scc1 {L('EMPTY')}")
+        # quiet step?  no input spike, no membrane at exactly 1.0 (tested out of line)
+        e(f"s_or_b64 {pair(S_PAIR)}, {pair(M_IN[0])}, {pair(M_IN[1])}")      # scc = some input spikes
+        e(f"s_cbranch_scc0 {L('NOIN')}")
         # The step's first active input is read straight into the accumulator (fl(0 + w) is w; a -0 weight leaves +0
         # instead of -0 there, which v + acc cannot see: a clipped v is never -0, and a carried-in -0 with no other
         # input ends as clip(+-0) = +0 either way): no zeroing and no adds for it.  Out of line: the first input in the
@@ -98,9 +96,7 @@ def gen():
         e(f"s_cbranch_scc1 {L('FIRST1')}")
         issue_input(0, ACC)
         o = ool.setdefault(name, []).append
-        o(f"{L('FIRST1')}:")
-        o(f"s_cmp_eq_u64 {pair(M_IN[1])}, 0")
-        o(f"s_cbranch_scc1 {L('ZERO')}")
+        o(f"{L('FIRST1')}:")                                     # no input in the lower group, so one in the upper
         lines_before = len(out)                                 # issue_input emits into the main stream: move its lines
         issue_input(1, ACC)
         moved = out[lines_before:]
@@ -108,7 +104,9 @@ def gen():
         for ln in moved:
             o(ln)
         o(f"s_branch {L('GRP1')}")
-        o(f"{L('ZERO')}:")
+        o(f"{L('NOIN')}:")                                       # no input spike: quiet unless a membrane is at 1.0
+        o(f"s_cmp_eq_u64 {pair(S_HOT)}, 0")
+        o(f"s_cbranch_scc1 {L('EMPTY')}")
         for j in range(4):
             o(f"v_mov_b32 v{ACC[j]}, 0")
         o(f"s_branch {L('IN_DONE1')}")

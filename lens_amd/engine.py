@@ -191,9 +191,49 @@ class LensEngine:
             step = Q   # several carried streams split the whole batch; do not re-split it
         for q0 in range(0, Q, step):
             fr = frames[q0:q0 + step]
+            if carry and self.n_streams == 1 and fr.shape[0] > self.CARRY_CHUNK:
+                self._carried_stream_pipelined(fr, out[q0:q0 + step])
+                continue
             self.feature_events(fr, carry=carry)
             self.output_counts(fr.shape[0], carry=carry, n_groups=n_groups, out=out[q0:q0 + step])
         return out
+
+    CARRY_CHUNK = 32    # queries per launch of the pipelined carried stream
+
+    def _carried_stream_pipelined(self, frames, out):
+        """One carried stream (the reference's semantics): both layers are sequential in the query index, each a
+        single wavefront per tile, but the output layer of a chunk of queries needs only that chunk's spike streams.
+        The feature layer therefore runs one chunk of queries ahead on a second HIP stream (same kernels, same order
+        per layer, identical results); the state of each layer is carried from launch to launch in v_feat / v_out."""
+        _need_cuda(frames, "frames")
+        assert frames.dtype == torch.uint8 and frames.is_contiguous()
+        Q = frames.shape[0]
+        assert frames[0].numel() == self.HW, "frame size does not match roi_dim"
+        self._workspace(Q)
+        L = _lib.lib()
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(main)          # frames are ready, and earlier readers of the workspace have finished
+        for c0 in range(0, Q, self.CARRY_CHUNK):
+            c1 = min(Q, c0 + self.CARRY_CHUNK)
+            fr, ev, nw = frames[c0:c1], self.events[c0:c1], self.nwords[c0:c1]
+            with torch.cuda.stream(side):
+                st = L.lens_feature_events(
+                    _ptr(fr), c1 - c0, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
+                    _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), 1, 1,
+                    _ptr(ev), self.cap, _ptr(nw), self.ev_scale, None, _stream())
+                _lib.check(st, "lens_feature_events")
+                done = torch.cuda.Event()
+                done.record(side)
+            main.wait_event(done)
+            o = out[c0:c1]
+            st = L.lens_output_counts(
+                _ptr(ev), self.cap, _ptr(nw), c1 - c0, _ptr(self.w2t), self.F, self.P, self.ldw2,
+                _ptr(self.v_out), self.P, 1, 1, _ptr(o), self.P, _stream())
+            _lib.check(st, "lens_output_counts")
+        side.wait_stream(main)          # the next call's feature launches must not overtake these output launches
 
     def forward_counts_static(self, frames, out, carry=False):
         """forward_counts through lens_forward_counts_static: the spike-stream workspace is the library's static

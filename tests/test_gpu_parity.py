@@ -58,6 +58,24 @@ def test_carry_state_persists_across_calls():
     assert np.array_equal(again.astype(np.int16), G["out_carry"])
 
 
+@pytest.mark.parametrize("chunk", [7, 32, 1000])
+def test_pipelined_carried_stream_is_identical(chunk):
+    """A single carried stream runs its feature layer a chunk of queries ahead of the output layer on a second HIP
+    stream (chunks of 7 and 32 queries; 1000 = one launch per layer, the unpipelined form): same counts, same carried
+    state, also when the call is repeated on the carried state."""
+    c, frames, w1, w2, gt, G = load_config("example")
+    f = torch.from_numpy(frames).cuda()
+    ref = _engine(w1, w2, c["roi"], c["dims"])
+    ref.CARRY_CHUNK = 1 << 30
+    eng = _engine(w1, w2, c["roi"], c["dims"])
+    eng.CARRY_CHUNK = chunk
+    for _ in range(2):
+        a, b = ref.forward_counts(f, carry=True), eng.forward_counts(f, carry=True)
+        assert torch.equal(a, b)
+        assert torch.equal(ref.v_feat, eng.v_feat) and torch.equal(ref.v_out, eng.v_out)
+    assert np.array_equal(eng.forward_counts(f[:5], carry=True).cpu().numpy(), ref.forward_counts(f[:5], carry=True).cpu().numpy())
+
+
 @pytest.mark.parametrize("tag", ["example", "sunset"])
 def test_seqmatch_and_recall_match_golden(tag, O):
     c, frames, w1, w2, gt, G = load_config(tag)

@@ -12,7 +12,11 @@
  *     The library never allocates, frees or synchronises; all work is enqueued on `stream`.
  *   - return value: 0 = LENS_OK; negative = argument error (nothing was enqueued);
  *     positive = hipError_t of the failed launch.  Nothing throws across the boundary.
- *   - re-entrant, no global state; one host thread per device.
+ *   - the entry points keep no state between calls except process-wide caches that are written once and
+ *     never change a result: the tuning overrides LENS_AMD_OUTPUT_PPL / LENS_AMD_TRAIN_LPR (read from the
+ *     environment at first use), two "kernel attributes checked" flags (atomic), and the per-device address
+ *     of the scratch array of lens_forward_counts_static (behind a mutex).  Calls from several host threads are
+ *     safe; work on one device is ordered by the streams the caller passes.
  *
  * Data layouts (row-major, last index fastest)
  *   frames      uint8  [Q][HW]            event-count frames (PNG pixels), HW = roi_dim*roi_dim
@@ -34,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 7
+#define LENS_AMD_ABI_VERSION 8
 
 /* Size of the library-owned device array behind lens_forward_counts_static (held once per GPU in use). */
 #define LENS_STATIC_SCRATCH_BYTES (64u << 20)
@@ -83,11 +87,17 @@ int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_co
 /* Words of `events` a query needs in the worst case: 2 * T * max(F, 1) rounded up to whole 32-word chunks. */
 size_t lens_event_capacity_words(int T, int F);
 
-/* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F and P) can consume
- * its streams: the byte stride of one W2^T row in the output kernel's LDS tile (1 if no tile fits in
- * LDS and the weights are read through L2).  The tile is 64, 128, 192 or 256 places wide, whichever
- * fits F and costs least for P, so the scale depends on both. */
-int lens_event_scale(int F, int P);
+/* Width, in places, of the W2^T tile lens_output_counts stages in LDS for these arguments: 64, 128, 192 or 256
+ * (whichever fits F and costs least), or 0 when no tile fits and the weights are read through L2.  `carry` and
+ * `n_groups` as passed to lens_output_counts (n_groups <= 0: its default).  With carried state every tile is
+ * walked by one wavefront of its own, so the width is chosen for the number of tiles resident at once rather than
+ * for the cost per place.  (No counterpart in the reference: a property of this library's kernels.) */
+int lens_output_tile_places(int F, int P, int carry, int n_groups);
+
+/* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F, P, carry and split) can
+ * consume its streams: the byte stride of one W2^T row in that tile (512 for the 128- and the 192-place tile,
+ * whose third places sit in a plane of their own; 1 if the weights are read through L2). */
+int lens_event_scale(int F, int P, int carry, int n_groups);
 
 /*
  * Frames -> feature-layer spike streams.  Replaces, for a batch of Q queries,
@@ -134,6 +144,8 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW,
  * n_groups / carry: as n_streams / carry of lens_feature_events (the two calls must use the same
  *        split).  carry != 0: d_vout [n_groups][ldv] carried state, read and written.
  * d_counts: float [Q][ldo], ldo >= P; columns >= P are not written.
+ * cap_words: words between two queries' streams, a multiple of 32 and >= 32 (whole 32-word chunks are read, the
+ *        first one of every query before its length is known); d_nwords[q] <= cap_words.
  */
 int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *d_nwords, int Q,
                        const float *d_w2t, int F, int P, int ldw2,
@@ -148,7 +160,8 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
  * still passes every input and output (arguments as in the two calls above; n_streams / carry apply to both
  * layers, d_vfeat [n_streams][F] and d_vout [n_streams][ldv] are the carried state when carry != 0).
  * Limit: 256-byte-rounded 4*Q + 4*Q*lens_event_capacity_words(T, F) <= LENS_STATIC_SCRATCH_BYTES (64 MiB: 167
- *        queries at T = 250, F = 200), otherwise LENS_ERR_SCRATCH and nothing is enqueued.
+ *        queries at T = 250, F = 200), otherwise LENS_ERR_SCRATCH.  Every argument of both layers is checked before the
+ *        first kernel is enqueued: a negative status means nothing was enqueued and no carried state has moved.
  * The array's device address is resolved on the first call on each device (hipGetSymbolAddress); make that first
  * call -- Q = 0 is enough -- outside any stream capture.  Every call on a GPU shares that GPU's array, which
  * keeps the previous call's contents (nothing in it has to start at zero: each call writes every word it later

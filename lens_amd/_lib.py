@@ -36,7 +36,8 @@ SIGNATURES = {
     "lens_accumulate_events": (_i, [_c_p, _c_p, _i, _i, _c_p, _c_p, _c_p]),
     "lens_build_threshold_codes": (_i, [_c_p, _i, _i, _c_p]),
     "lens_event_capacity_words": (ctypes.c_size_t, [_i, _i]),
-    "lens_event_scale": (_i, [_i, _i]),
+    "lens_output_tile_places": (_i, [_i, _i, _i, _i]),
+    "lens_event_scale": (_i, [_i, _i, _i, _i]),
     "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
                                  _c_p, _i, _c_p, _i, _c_p, _c_p]),
     "lens_output_counts": (_i, [_c_p, _i, _c_p, _i, _c_p, _i, _i, _i, _c_p, _i, _i, _i, _c_p, _i, _c_p]),
@@ -54,7 +55,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class LensAmdError(RuntimeError):

@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 #include "../../include/lens_amd.h"
@@ -56,6 +57,7 @@ constexpr int EV_CHUNK = 16;
 constexpr int EV_WORDS = 2 * EV_CHUNK;
 constexpr int OUT_ORDER_MAX = 512;    // largest query group the output kernel sorts by stream length
 constexpr int OUT_BOOK_BYTES = OUT_ORDER_MAX * 6 + 16;   // its lengths, order and query counter, behind the LDS tile
+constexpr int OUT_BOOK_CARRY_BYTES = 16;                 // carried state: the counter word only
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 {
@@ -615,7 +617,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
     unsigned char *book = smem + (W_LDS ? (size_t)a.F * PT * 4 : 0);
     uint32_t *s_len = reinterpret_cast<uint32_t *>(book);                              // [OUT_ORDER_MAX]
     uint16_t *s_order = reinterpret_cast<uint16_t *>(book + OUT_ORDER_MAX * 4);          // longest stream first (when the group is small enough to rank)
-    int &s_next = *reinterpret_cast<int *>(book + OUT_ORDER_MAX * 6);
+    int &s_next = *reinterpret_cast<int *>(book + (a.carry ? 0 : OUT_ORDER_MAX * 6));   // carried state: the book is this word only
     if (threadIdx.x == 0) s_next = 0;
     if constexpr (W_LDS) {
         float4 *dst = reinterpret_cast<float4 *>(smem);
@@ -1268,16 +1270,28 @@ LENS_TRAIN_KERNEL(512, 4, 3) LENS_TRAIN_KERNEL(512, 8, 5) LENS_TRAIN_KERNEL(1024
 #undef LENS_TRAIN_KERNEL
 
 // y[s][o] = clamp(chain_n fmaf(x[s][n], w[o][n]) - thr[o], 0, 1)  (train_model.py:163-168)
+// A workgroup owns 64 outputs x 4 samples.  The 64 x 64 pieces of w are staged through LDS (loaded row-wise, coalesced;
+// read column-wise, the odd row stride keeps the banks apart); x[s][n] is one broadcast load per wavefront.
 __global__ void __launch_bounds__(256) k_layer_forward_clamped(const float *__restrict__ x, int S, int ldx,
                                                                const float *__restrict__ w, int ldw,
                                                                const float *__restrict__ thr, int n_in, int n_out,
                                                                float *__restrict__ y, int ldy)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)S * n_out) return;
-    const int s = (int)(i / n_out), o = (int)(i - (long long)s * n_out);
+    __shared__ float sw[64][65];
+    const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int o0 = blockIdx.x * 64, o = o0 + lane;
+    const int s = blockIdx.y * 4 + row;
+    const float *xs = x + (size_t)(s < S ? s : 0) * ldx;
     float acc = 0.0f;
-    for (int n = 0; n < n_in; ++n) acc = __builtin_fmaf(x[(size_t)s * ldx + n], w[(size_t)o * ldw + n], acc);
+    for (int n0 = 0; n0 < n_in; n0 += 64) {
+        __syncthreads();
+        for (int r = row; r < 64; r += 4)
+            sw[r][lane] = (o0 + r < n_out && n0 + lane < n_in) ? w[(size_t)(o0 + r) * ldw + n0 + lane] : 0.0f;
+        __syncthreads();
+        const int kn = (n_in - n0) < 64 ? (n_in - n0) : 64;
+        for (int k = 0; k < kn; ++k) acc = __builtin_fmaf(xs[n0 + k], sw[lane][k], acc);
+    }
+    if (s >= S || o >= n_out) return;
     float v = acc - thr[o];
     v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f);
     y[(size_t)s * ldy + o] = v;
@@ -1330,6 +1344,7 @@ __global__ void __launch_bounds__(256) k_sad_matrix(const uint8_t *__restrict__ 
 // launch helpers
 // ------------------------------------------------------------------------------------------
 constexpr int LDS_BUDGET = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
+constexpr int NUM_CUS = 256;             // MI355X
 
 template <typename K>
 int set_lds(K kernel, size_t bytes)
@@ -1354,12 +1369,12 @@ int launch_feature(const FeatArgs &a, hipStream_t st)
         if constexpr (NPL == 2 && FPL == 4) {
             // The assembly step loop addresses the staged tables from LDS address 0: the kernel must not own any
             // static LDS (a __shared__ variable added to it would shift the dynamic block and silently break it).
-            static int lds_base_checked = 0;
-            if (!lds_base_checked) {
+            static std::atomic<int> lds_base_checked{0};
+            if (!lds_base_checked.load(std::memory_order_acquire)) {
                 hipFuncAttributes at;
                 if (hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k))) return (int)e;
                 if (at.sharedSizeBytes != 0) return LENS_ERR_UNSUPPORTED;
-                lds_base_checked = 1;
+                lds_base_checked.store(1, std::memory_order_release);
             }
         }
         if (int e = set_lds(k, lds)) return e;
@@ -1384,17 +1399,19 @@ int dispatch_feature_f(const FeatArgs &a, hipStream_t st)
 template <int PPL, bool W_LDS>
 int launch_output(const OutArgs &a, int threads, hipStream_t st)
 {
-    const size_t lds = (W_LDS ? (size_t)a.F * 64 * PPL * 4 : 0) + OUT_BOOK_BYTES;
+    // carried state: one wavefront per workgroup, no query ranking -- only the (unused) counter word behind the tile,
+    // so that three 50 KB tiles still fit one CU
+    const size_t lds = (W_LDS ? (size_t)a.F * 64 * PPL * 4 : 0) + (a.carry ? OUT_BOOK_CARRY_BYTES : OUT_BOOK_BYTES);
     auto k = k_output_counts<PPL, W_LDS>;
     if constexpr (PPL == 3) {
         // The assembly loop reads the third places relative to LDS address 0: the kernel must not own static LDS
         // (a __shared__ variable added to it would shift the dynamic block and silently break the addressing).
-        static int lds_base_checked = 0;
-        if (!lds_base_checked) {
+        static std::atomic<int> lds_base_checked{0};
+        if (!lds_base_checked.load(std::memory_order_acquire)) {
             hipFuncAttributes at;
             if (hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k))) return (int)e;
             if (at.sharedSizeBytes != 0) return LENS_ERR_UNSUPPORTED;
-            lds_base_checked = 1;
+            lds_base_checked.store(1, std::memory_order_release);
         }
     }
     if (int e = set_lds(k, lds)) return e;
@@ -1497,32 +1514,51 @@ size_t lens_event_capacity_words(int T, int F)
 }
 
 // Places per lane of the output kernel for F features and P places: among the tiles whose W2^T columns fit in LDS,
-// the one with the least work, = places after padding P to whole tiles x the measured relative time per place of
-// that width (wider tiles spread the per-event scalar work and branches over more places; measured at 100 000
-// places: 1.79 / 1 / 0.87 / 0.69 for 64 / 128 / 192 / 256).  A database of a few tiles runs as a single round of
+// the one with the least work.  0 = no tile fits (weights are read through L2).
+// Batch mode (carry == 0): places after padding P to whole tiles x the measured relative time per place of that
+// width (wider tiles spread the per-event scalar work and branches over more places; measured at 100 000 places:
+// 1.79 / 1 / 0.87 / 0.69 for 64 / 128 / 192 / 256).  A database of a few tiles runs as a single round of
 // workgroups, where the coarser (query, tile) items of the wide tiles balance worse: measured +7 % at 1000 places.
-// 0 = no tile fits.
-static int output_ppl(int F, int P)
+// Carried state (carry != 0): a tile is walked by ONE wavefront (a workgroup of its own, with its own copy of the
+// tile in LDS), so what counts is how many tiles are resident at once -- 160 KiB / tile bytes per CU -- and how long
+// one wavefront alone takes per query, which grows slowly with the width (CARRY_REL, measured): time ~ rounds of
+// resident workgroups x that.
+static int output_ppl(int F, int P, int carry, int n_groups)
 {
-    static const struct { int ppl; double rel; } widths[] = {{4, 0.69}, {3, 0.87}, {2, 1.00}, {1, 1.79}};
+    static const struct { int ppl; double rel; double carry_rel; } widths[] = {
+        {4, 0.69, 1.50}, {3, 0.87, 1.27}, {2, 1.00, 1.00}, {1, 1.79, 0.86}};   // carry: 15.9 / 18.5 / 23.4 us per query for 64 / 128 / 192
     // tuning override: LENS_AMD_OUTPUT_PPL=1..4 forces that width wherever it fits (read once)
     static const int forced = [] { const char *e = getenv("LENS_AMD_OUTPUT_PPL"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 4 && (size_t)F * 64 * forced * 4 <= (size_t)LDS_BUDGET - 4096) return forced;
     int best = 0;
     double best_cost = 0.0;
     for (const auto &c : widths) {
-        if ((size_t)F * 64 * c.ppl * 4 > (size_t)LDS_BUDGET - 4096) continue;
+        const size_t tile_bytes = (size_t)F * 64 * c.ppl * 4;
+        if (tile_bytes > (size_t)LDS_BUDGET - 4096) continue;
         const int pt = 64 * c.ppl;
         const size_t tiles = ((size_t)(P > 0 ? P : 1) + pt - 1) / pt;
-        const double cost = (double)tiles * pt * c.rel * (c.ppl >= 3 && tiles < 128 ? 1.07 : 1.0);
+        double cost;
+        if (carry) {
+            const size_t per_cu = (size_t)LDS_BUDGET / (tile_bytes + 512);   // allocation granularity
+            const size_t resident = NUM_CUS * (per_cu < 1 ? 1 : per_cu > 32 ? 32 : per_cu);
+            const size_t wgs = tiles * (size_t)(n_groups > 0 ? n_groups : 1);
+            cost = (double)((wgs + resident - 1) / resident) * c.carry_rel;
+        } else {
+            cost = (double)tiles * pt * c.rel * (c.ppl >= 3 && tiles < 128 ? 1.07 : 1.0);
+        }
         if (!best || cost < best_cost) { best = c.ppl; best_cost = cost; }
     }
     return best;
 }
 
-int lens_event_scale(int F, int P)
+int lens_output_tile_places(int F, int P, int carry, int n_groups)
 {
-    const int ppl = output_ppl(F, P);
+    return 64 * output_ppl(F, P, carry, n_groups);
+}
+
+int lens_event_scale(int F, int P, int carry, int n_groups)
+{
+    const int ppl = output_ppl(F, P, carry, n_groups);
     if (ppl == 3) return 512;   // the 128 places read as pairs; the 64 third places sit in a plane of half that stride
     return ppl ? 64 * ppl * 4 : 1;
 }
@@ -1561,19 +1597,21 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
 {
     if (!d_events || !d_nwords || !d_w2t || !d_counts) return LENS_ERR_NULL;
     if (carry && !d_vout) return LENS_ERR_NULL;
-    if (Q < 0 || F <= 0 || P <= 0 || ldw2 < P || ldo < P || cap_words <= 0 || (carry && ldv < P)) return LENS_ERR_SIZE;
+    if (Q < 0 || F <= 0 || P <= 0 || ldw2 < P || ldo < P || (carry && ldv < P)) return LENS_ERR_SIZE;
+    // the kernels read whole 32-word chunks (the first one before they look at the stream's length)
+    if (cap_words < EV_WORDS || (cap_words & (EV_WORDS - 1))) return LENS_ERR_SIZE;
     if ((ldw2 & 255) || ((uintptr_t)d_w2t & 15)) return LENS_ERR_ALIGN;
     if (Q == 0) return LENS_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (carry && n_groups <= 0) n_groups = 1;
+    if (carry && n_groups > Q) return LENS_ERR_SIZE;
 
-    const int ppl = output_ppl(F, P);
+    const int ppl = output_ppl(F, P, carry, n_groups);
     const int pt = 64 * (ppl ? ppl : 4);
     const int ntiles = (P + pt - 1) / pt;
 
     int threads;
     if (carry) {
-        if (n_groups <= 0) n_groups = 1;
-        if (n_groups > Q) return LENS_ERR_SIZE;
         threads = 64;
     } else {
         threads = 1024;
@@ -1634,9 +1672,18 @@ int lens_forward_counts_static(const uint8_t *d_frames, int Q, int HW, const int
     uint32_t *events = reinterpret_cast<uint32_t *>(base + nwords_bytes);
     // every word the output kernel reads is written by the feature kernel of this call (nwords[q] and the first
     // nwords[q] words of each stream), so nothing in the array has to start at zero
-    const int split = carry ? n_streams : 0;
+    int split = carry ? n_streams : 0;
+    if (carry && (split <= 0 || split > Q)) {
+        if (split > Q) return LENS_ERR_SIZE;
+        split = 1;
+    }
+    // everything lens_output_counts would refuse is refused here, before the feature layer is enqueued: a call that
+    // fails must not leave the two layers' carried states out of step
+    if (!d_w2t || !d_counts || (carry && !d_vout)) return LENS_ERR_NULL;
+    if (P <= 0 || ldw2 < P || ldo < P || (carry && ldv < P)) return LENS_ERR_SIZE;
+    if ((ldw2 & 255) || ((uintptr_t)d_w2t & 15)) return LENS_ERR_ALIGN;
     if (int e = lens_feature_events(d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, d_vfeat, split, carry,
-                                    events, (int)cap, nwords, lens_event_scale(F, P), nullptr, stream))
+                                    events, (int)cap, nwords, lens_event_scale(F, P, carry, split), nullptr, stream))
         return e;
     return lens_output_counts(events, (int)cap, nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, split, carry, d_counts, ldo,
                               stream);
@@ -1699,9 +1746,12 @@ int lens_layer_forward_clamped(const float *d_x, int S, int ldx, const float *d_
     if (!d_x || !d_w || !d_thr || !d_y) return LENS_ERR_NULL;
     if (S < 0 || n_in <= 0 || n_out <= 0 || ldx < n_in || ldw < n_in || ldy < n_out) return LENS_ERR_SIZE;
     if (S == 0) return LENS_OK;
-    const long long total = (long long)S * n_out;
-    hipLaunchKernelGGL(k_layer_forward_clamped, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       d_x, S, ldx, d_w, ldw, d_thr, n_in, n_out, d_y, ldy);
+    for (int s0 = 0; s0 < S; s0 += 4 * 65535) {   // grid.y is limited to 65535 blocks of 4 samples
+        const int ns = (S - s0) < 4 * 65535 ? (S - s0) : 4 * 65535;
+        hipLaunchKernelGGL(k_layer_forward_clamped, dim3((unsigned)((n_out + 63) / 64), (unsigned)((ns + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, d_x + (size_t)s0 * ldx, ns, ldx, d_w, ldw, d_thr, n_in, n_out,
+                           d_y + (size_t)s0 * ldy, ldy);
+    }
     return (int)hipGetLastError();
 }
 

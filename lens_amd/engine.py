@@ -122,7 +122,6 @@ class LensEngine:
         # the spike-stream workspace is sized for the worst case (every feature spikes every step):
         # keep it below ~4 GB by limiting the queries processed per launch
         self.max_batch = max(1, min(self.max_batch, (4 << 30) // (4 * self.cap)))
-        self.ev_scale = int(_lib.lib().lens_event_scale(self.F, self.P))
         self.n_streams = 1
         self.reset_state()
         self._ws_q = 0
@@ -133,6 +132,19 @@ class LensEngine:
         self.n_streams = int(n_streams)
         self.v_feat = torch.zeros((self.n_streams, self.F), dtype=torch.float32, device=self.device)
         self.v_out = torch.zeros((self.n_streams, self.P), dtype=torch.float32, device=self.device)
+
+    def event_scale(self, carry=False):
+        """The `ev_scale` of the spike streams for this mode (the output kernel's tile width depends on it:
+        with carried state a tile is walked by one wavefront and narrower tiles keep more of them resident)."""
+        return int(_lib.lib().lens_event_scale(self.F, self.P, int(bool(carry)), self.n_streams if carry else 0))
+
+    def tile_places(self, carry=False):
+        """Places per LDS weight tile of the output kernel in this mode (0: weights read through L2)."""
+        return int(_lib.lib().lens_output_tile_places(self.F, self.P, int(bool(carry)), self.n_streams if carry else 0))
+
+    @property
+    def ev_scale(self):
+        return self.event_scale(False)
 
     def _workspace(self, Q):
         if Q > self._ws_q:
@@ -154,7 +166,7 @@ class LensEngine:
         st = _lib.lib().lens_feature_events(
             _ptr(frames), Q, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
             _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), n_streams, int(carry),
-            _ptr(self.events), self.cap, _ptr(self.nwords), self.ev_scale, _ptr(spk), _stream())
+            _ptr(self.events), self.cap, _ptr(self.nwords), self.event_scale(carry), _ptr(spk), _stream())
         _lib.check(st, "lens_feature_events")
         return spk
 
@@ -183,7 +195,8 @@ class LensEngine:
     def forward_counts(self, frames, carry=False, n_groups=0):
         """The query loop of LENS.evaluate (lens/run_model.py:229-246) for a batch of frames:
         uint8 [Q,H,W] -> similarity-matrix rows float32 [Q,P].  carry=True integrates the queries
-        in order with the membrane state carried across them (and across calls)."""
+        in order with the membrane state carried across them (and across calls); the split into carried streams is
+        the engine's `n_streams` (reset_state), `n_groups` applies to the batch mode only."""
         Q = frames.shape[0]
         out = torch.empty((Q, self.P), dtype=torch.float32, device=self.device)
         step = self.max_batch
@@ -214,26 +227,37 @@ class LensEngine:
         main = torch.cuda.current_stream(self.device)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
+            self._side_done = [torch.cuda.Event(), torch.cuda.Event()]   # chunk k uses event k & 1
         side = self._side
+        scale = self.event_scale(True)
+        # The side stream uses the spike-stream workspace, v_feat and the caller's frames without telling the caching
+        # allocator (no record_stream).  That is sound only because EVERY side-stream launch is joined to the main
+        # stream before this method returns -- also when a launch fails half way (the finally below): after the join,
+        # frees and re-allocations ordered on the main stream (reset_state, a larger workspace) come after the side
+        # stream's work.  An event of the pair is re-recorded two chunks later, after the main stream's wait on it
+        # was enqueued (a wait refers to the record that preceded it).
         side.wait_stream(main)          # frames are ready, and earlier readers of the workspace have finished
-        for c0 in range(0, Q, self.CARRY_CHUNK):
-            c1 = min(Q, c0 + self.CARRY_CHUNK)
-            fr, ev, nw = frames[c0:c1], self.events[c0:c1], self.nwords[c0:c1]
-            with torch.cuda.stream(side):
-                st = L.lens_feature_events(
-                    _ptr(fr), c1 - c0, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
-                    _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), 1, 1,
-                    _ptr(ev), self.cap, _ptr(nw), self.ev_scale, None, _stream())
-                _lib.check(st, "lens_feature_events")
-                done = torch.cuda.Event()
-                done.record(side)
-            main.wait_event(done)
-            o = out[c0:c1]
-            st = L.lens_output_counts(
-                _ptr(ev), self.cap, _ptr(nw), c1 - c0, _ptr(self.w2t), self.F, self.P, self.ldw2,
-                _ptr(self.v_out), self.P, 1, 1, _ptr(o), self.P, _stream())
-            _lib.check(st, "lens_output_counts")
-        side.wait_stream(main)          # the next call's feature launches must not overtake these output launches
+        try:
+            for k, c0 in enumerate(range(0, Q, self.CARRY_CHUNK)):
+                c1 = min(Q, c0 + self.CARRY_CHUNK)
+                fr, ev, nw = frames[c0:c1], self.events[c0:c1], self.nwords[c0:c1]
+                done = self._side_done[k & 1]
+                with torch.cuda.stream(side):
+                    st = L.lens_feature_events(
+                        _ptr(fr), c1 - c0, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
+                        _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), 1, 1,
+                        _ptr(ev), self.cap, _ptr(nw), scale, None, _stream())
+                    _lib.check(st, "lens_feature_events")
+                    done.record(side)
+                main.wait_event(done)
+                o = out[c0:c1]
+                st = L.lens_output_counts(
+                    _ptr(ev), self.cap, _ptr(nw), c1 - c0, _ptr(self.w2t), self.F, self.P, self.ldw2,
+                    _ptr(self.v_out), self.P, 1, 1, _ptr(o), self.P, _stream())
+                _lib.check(st, "lens_output_counts")
+        finally:
+            main.wait_stream(side)      # join: nothing of this call is left running on the side stream unseen by main
+            side.wait_stream(main)      # the next call's feature launches must not overtake these output launches
 
     def forward_counts_static(self, frames, out, carry=False):
         """forward_counts through lens_forward_counts_static: the spike-stream workspace is the library's static

@@ -8,7 +8,10 @@ sequence matcher and (for large databases) the top-k -- runs in liblens_amd.so o
 Semantics kept from the reference, on purpose:
   * the membrane state is carried from query to query (the reference never calls reset_states(),
     lens/run_model.py:234-242); `--amd_state reset` selects the per-query-reset variant instead;
-  * Recall@N uses numpy's default argsort on the full matrix, like lens/src/metrics.py:219;
+  * Recall@N uses numpy's default argsort on the full matrix, like lens/src/metrics.py:219 -- for a small
+    matrix.  From 2^24 entries on (or with `--amd_topk always`) it comes from the GPU's fused sequence matcher +
+    top-25, whose tie policy is explicit (score descending, then place index descending = what a STABLE ascending
+    argsort + [-K:] returns) and is written to the log; the full matrix is then neither copied to the host nor sorted;
   * sequence_length == 0 skips the matcher and leaves the matrix untransposed (run_model.py:253-254).
 There is no CPU execution path: without a ROCm GPU (or with --nocuda) construction fails.
 """
@@ -22,9 +25,10 @@ from . import blitnet as bn
 from ._lib import LensAmdError
 from .dataset import CustomImageDataset
 from .loggers import model_logger
-from .metrics import recallAtK, createPR
+from .metrics import recallAtK, recall_from_topk, createPR
 
 RECALL_N = [1, 5, 10, 15, 20, 25]
+TOPK_AUTO_ENTRIES = 1 << 24      # places x queries from which --amd_topk auto ranks on the GPU
 
 
 def format_table(field_names, row):
@@ -108,33 +112,54 @@ class LENS(nn.Module):
         else:
             frames = test_loader.frames() if hasattr(test_loader, "frames") else test_loader
         counts = self.similarity_rows(frames)
-        out = counts.cpu().numpy().astype(np.float64)
-        out = np.reshape(out, (model.query_places, model.reference_places))
-        if self.sequence_length != 0:
-            S_dev = seqmatch(counts, self.sequence_length)              # query-major on the device
-            dist_matrix_seq = np.ascontiguousarray(S_dev.cpu().numpy().T)   # reference orientation
+        assert tuple(counts.shape) == (model.query_places, model.reference_places)
+        L = self.sequence_length
+        mode = getattr(self, "amd_topk", "auto")
+        use_topk = self.matching and L != 0 and max(RECALL_N) <= model.reference_places - L + 1 and (
+            mode == "always" or (mode == "auto" and counts.numel() >= TOPK_AUTO_ENTRIES))
+        # the full matrix on the host: always for a small one (the reference's artefacts), for a large one only if asked
+        want_matrix = not use_topk or mode == "always" or self.sim_mat or self.PR_curve
+        dist_matrix_seq = None
+        if want_matrix:
+            if L != 0:
+                S_dev = seqmatch(counts, L)                                     # query-major on the device
+                dist_matrix_seq = np.ascontiguousarray(S_dev.cpu().numpy().T)   # reference orientation
+            else:
+                dist_matrix_seq = counts.cpu().numpy().astype(np.float64)
+            np.save(os.path.join(self.output_folder, "similarity_matrix.npy"), dist_matrix_seq)
+            plt.imshow(dist_matrix_seq)
+            plt.colorbar()
+            plt.savefig(os.path.join(self.output_folder, "distance_matrix_lens.pdf"))
+            plt.close()
         else:
-            dist_matrix_seq = out
-        np.save(os.path.join(self.output_folder, "similarity_matrix.npy"), dist_matrix_seq)
-
-        plt.imshow(dist_matrix_seq)
-        plt.colorbar()
-        plt.savefig(os.path.join(self.output_folder, "distance_matrix_lens.pdf"))
-        plt.close()
+            model.logger.info(f"similarity matrix {model.reference_places} x {model.query_places}: kept on the GPU, "
+                              "not written or plotted (--sim_mat / --PR_curve / --amd_topk always bring it to the host)")
 
         R = []
         if self.matching:
             GT = np.load(os.path.join(self.data_dir, self.dataset, self.camera,
                                       self.reference + "_" + self.query + "_GT.npy"))
-            if self.sequence_length != 0:
-                GT = GT[self.sequence_length - 2:-1, self.sequence_length - 2:-1]
+            if L != 0:
+                GT = GT[L - 2:-1, L - 2:-1]
             GTtol = create_GTtol(GT, distance=self.GT_tolerance).T
-            plt.imshow(GTtol)
-            plt.colorbar()
-            plt.savefig(os.path.join(self.output_folder, "GTtol.pdf"))
-            plt.close()
-            for n in RECALL_N:
-                R.append(round(recallAtK(dist_matrix_seq, GTtol, K=n), 2))
+            if want_matrix:
+                plt.imshow(GTtol)
+                plt.colorbar()
+                plt.savefig(os.path.join(self.output_folder, "GTtol.pdf"))
+                plt.close()
+            if use_topk:
+                from .engine import seqmatch_topk
+                idx, _ = seqmatch_topk(counts, L, max(RECALL_N))
+                idx = idx.cpu().numpy()
+                np.save(os.path.join(self.output_folder, "topk_places.npy"), idx)
+                for n in RECALL_N:
+                    R.append(round(recall_from_topk(idx, GTtol, n), 2))
+                model.logger.info(f"Recall@N from the GPU top-{max(RECALL_N)} lists; ties: higher score first, then the "
+                                  "larger place index (a stable ascending argsort + [-K:]; the reference's default "
+                                  "argsort leaves the order of ties unspecified)")
+            else:
+                for n in RECALL_N:
+                    R.append(round(recallAtK(dist_matrix_seq, GTtol, K=n), 2))
             model.logger.info(format_table(["N"] + [str(n) for n in RECALL_N], ["Recall"] + R))
 
         if self.sim_mat:

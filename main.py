@@ -72,6 +72,10 @@ def build_parser():
     p.add_argument("--amd_state", choices=["carry", "reset"], default="carry",
                    help="carry: reference semantics (state persists from query to query); "
                         "reset: zero the state per query (batch-parallel)")
+    p.add_argument("--amd_topk", choices=["auto", "always", "never"], default="auto",
+                   help="Recall@N from the GPU's fused sequence-match + top-25 instead of a host argsort of the full "
+                        "matrix (auto: when places x queries exceeds 2^24; the full-matrix artefacts are then skipped "
+                        "unless --sim_mat / --PR_curve ask for them)")
     return p
 
 

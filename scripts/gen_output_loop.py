@@ -34,6 +34,9 @@ WPAIR, WTHIRD = 64, 96          # weights: event i -> v[64+2i : 65+2i] and (thre
 EV_CHUNK = 16
 READ_GROUP = 16                 # events whose addresses are computed before their reads are issued
 PAIR_FIRST = True               # a step's first two events enter the accumulator with one add per place
+# Timing probes only (wrong results): LENS_GEN_PROBE=nowait drops the wait for the weight reads (how much of a chunk's
+# time is their exposed latency), =nolds drops the reads themselves.  Never set for a committed .inc file.
+PROBE = os.environ.get("LENS_GEN_PROBE", "")
 
 
 def gen(ppl):
@@ -97,12 +100,14 @@ def gen(ppl):
                         # that uses it: the 8-byte read.)  Microbenchmark of the whole mix: -5 %.
                         e(f"s_lshr_b32 m0, {off0 if i == 0 else off(i)}, 1")
                     for ln in read(i, W(i)[0]):
-                        e(ln)
+                        if PROBE != "nolds":
+                            e(ln)
             e("s_add_u32 %[soff], %[soff], 0x80")
             e("s_sub_u32 %[nch], %[nch], 1")          # borrow (scc) = no chunk follows; [nch] = chunks after the next one
             # LDS and scalar memory share one counter and scalar loads return out of order: the reads must have landed
             # before the prefetch is issued, or waiting for them would wait for the prefetch as well
-            e("s_waitcnt lgkmcnt(0)")
+            if PROBE != "nowait":
+                e("s_waitcnt lgkmcnt(0)")
 
         # The chunk's flag first: a chunk whose counts are all 1 (96 % at the benchmark's density) uses its first offset
         # word as it is; the others get a copy of the read phase that masks the flag off, behind the loop.
@@ -279,9 +284,11 @@ def gen(ppl):
 
 
 def main():
+    import sys
     here = os.path.dirname(os.path.abspath(__file__))
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "lens_amd", "csrc")
     for ppl in (1, 2, 3, 4):
-        path = os.path.join(here, "..", "lens_amd", "csrc", f"output_loop_p{ppl}.inc")
+        path = os.path.join(out_dir, f"output_loop_p{ppl}.inc")
         lines = gen(ppl)
         with open(path, "w") as f:
             f.write(f"// GENERATED by scripts/gen_output_loop.py -- do not edit.  gfx950 chunk loop of "

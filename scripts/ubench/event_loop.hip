@@ -212,6 +212,14 @@ KERNEL4(k_mix16p3s, "s_lshl_b32 s20, %6, 9\n" P3S_RD16 "s_waitcnt lgkmcnt(0)\n" 
 #define T2_RD16 T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD T2_RD
 KERNEL4(k_mix16t2, "s_lshl_b32 s20, %6, 9\n" T2_RD16 "s_waitcnt lgkmcnt(0)\n" MIX_EVS "s_branch 90f\n" MIX_STEPN(1) MIX_STEPN(2) MIX_STEPN(3) MIX_STEPN(4) "90:\n")
 
+// the shipped three-place mix (p3t) with the weight reads software-pipelined over chunks: wait for the reads issued one
+// chunk earlier, issue the next chunk's reads (a second set of weight registers in the real kernel), then integrate
+KERNEL4(k_mix16p3tpre, "s_lshl_b32 s20, %6, 9\n s_waitcnt lgkmcnt(0)\n" P3T_RD16 P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+// ... and with no LDS read at all (address adds and M0 shifts kept): what the reads' issue slots cost
+#define P3T_NR "s_lshr_b32 m0, s20, 1\n"
+#define P3T_NR16 P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_AD P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR P3T_NR
+KERNEL4(k_mix16p3tnolds, "s_lshl_b32 s20, %6, 9\n" P3T_NR16 P3_EVS "s_branch 90f\n" P3_STEP(1) P3_STEP(2) P3_STEP(3) P3_STEP(4) "90:\n")
+
 template <typename K>
 void run(const char *name, K kern) {
     unsigned long long *d; hipMalloc(&d, 512 * 16 * 8);
@@ -241,7 +249,7 @@ int main(int argc, char **argv) {
     RUN("valu3+s", k_v3s) RUN("valu3+sb", k_v3sb) RUN("ppl4", k_p4)
     RUN("ev_s2", k_s2) RUN("ev_pk", k_pk) RUN("iaf_s", k_iafs) RUN("iaf_p", k_iafp)
     RUN("mix16", k_mix16)   // "events" in its printout are whole 16-event chunks / 8
-    RUN("mix16p3", k_mix16p3) RUN("mix16p3s", k_mix16p3s) RUN("mix16p3t", k_mix16p3t) RUN("mix16p3u", k_mix16p3u) RUN("mix16p3n", k_mix16p3n) RUN("mix16t2", k_mix16t2) RUN("mix16p3v", k_mix16p3v) RUN("mix16p3b", k_mix16p3b) RUN("mix16p3c", k_mix16p3c) RUN("mix16n", k_mix16n)
+    RUN("mix16p3", k_mix16p3) RUN("mix16p3s", k_mix16p3s) RUN("mix16p3t", k_mix16p3t) RUN("mix16p3tpre", k_mix16p3tpre) RUN("mix16p3tnolds", k_mix16p3tnolds) RUN("mix16p3u", k_mix16p3u) RUN("mix16p3n", k_mix16p3n) RUN("mix16t2", k_mix16t2) RUN("mix16p3v", k_mix16p3v) RUN("mix16p3b", k_mix16p3b) RUN("mix16p3c", k_mix16p3c) RUN("mix16n", k_mix16n)
     RUN("mix16z", k_mix16z) RUN("mix16v", k_mix16v) RUN("mix16zv", k_mix16zv)
     RUN("mix16pre", k_mix16pre) RUN("mix16nolds", k_mix16nolds) RUN("mix16nostep", k_mix16nostep) RUN("mix16inl", k_mix16inl)
     RUN("add2", k_a2) RUN("add2+nt", k_nt) RUN("add2+tk", k_tk) RUN("add2+tk2", k_tk2) RUN("add2+call", k_call)

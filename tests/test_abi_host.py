@@ -42,14 +42,20 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     assert L.lens_accumulate_events(p, p, 1, 500, p, p, None) == -3          # roi too large for the LDS histogram
     assert L.lens_seqmatch_topk(p, 4, 8, 4, 2, 65, 0, p, p, None) == -2       # K > 64
     assert L.lens_seqmatch_topk(p, 1, 8, 4, 2, 5, 0, p, p, None) == -2        # fewer queries than L
-    assert L.lens_output_counts(p, 16, p, 1, p, 4, 10, 100, None, 10, 1, 0, p, 10, None) == -4   # ldw2 % 256
+    assert L.lens_output_counts(p, 32, p, 1, p, 4, 10, 100, None, 10, 1, 0, p, 10, None) == -4   # ldw2 % 256
+    assert L.lens_output_counts(p, 16, p, 1, p, 4, 10, 256, None, 10, 1, 0, p, 10, None) == -2   # streams hold whole 32-word chunks
+    assert L.lens_output_counts(p, 48, p, 1, p, 4, 10, 256, None, 10, 1, 0, p, 10, None) == -2
     assert L.lens_amd_strerror(-2).decode().startswith("a size")
     assert L.lens_event_capacity_words(250, 200) == 100000
     assert L.lens_event_capacity_words(3, 0) == 32
     # tile width by (F, P): 256 places while they fit (F <= 156), else 192 or 128 -- whichever pads P less, times its rate
-    assert L.lens_event_scale(63, 1000) == 1024 and L.lens_event_scale(5000, 1000) == 1
-    assert L.lens_event_scale(200, 100000) == 512 and L.lens_event_scale(200, 1000) == 512
-    assert L.lens_event_scale(200, 64) == 256 and L.lens_event_scale(300, 100000) == 512
+    assert L.lens_event_scale(63, 1000, 0, 0) == 1024 and L.lens_event_scale(5000, 1000, 0, 0) == 1
+    assert L.lens_event_scale(200, 100000, 0, 0) == 512 and L.lens_event_scale(200, 1000, 0, 0) == 512
+    assert L.lens_event_scale(200, 64, 0, 0) == 256 and L.lens_event_scale(300, 100000, 0, 0) == 512
+    # tile widths: batch mode by cost per place; carried state (one wavefront per tile) by tiles resident at once
+    assert [L.lens_output_tile_places(200, p, 0, 0) for p in (64, 1000, 100000)] == [64, 128, 192]
+    assert L.lens_output_tile_places(100, 100000, 0, 0) == 256 and L.lens_output_tile_places(700, 5, 0, 0) == 0
+    assert L.lens_output_tile_places(200, 100000, 1, 1) == 64 and L.lens_event_scale(200, 100000, 1, 1) == 256
 
 
 def test_product_refuses_to_run_without_gpu():

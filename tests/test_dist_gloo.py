@@ -59,10 +59,16 @@ def _worker(rank, world, port, out, L, K, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,P,L,K", [(2, 301, 2, 25), (3, 97, 3, 10), (2, 40, 1, 25)])
+# the last case is the benchmark's multi-GPU shape: 100 000 places over 8 ranks (12 500 places + 1 halo row each,
+# except that the 99 999 sequence-matched places do not divide evenly), L = 2, top-25
+@pytest.mark.parametrize("world,P,L,K", [(2, 301, 2, 25), (3, 97, 3, 10), (2, 40, 1, 25), (8, 100000, 2, 25)])
 def test_sharded_topk_allgather_merge(world, P, L, K):
     rng = np.random.default_rng(world * 100 + P)
     out = rng.integers(0, 5, size=(17, P)).astype(np.float32)       # many ties
+    if P >= 1000:                                                   # ... and winners that straddle shard borders
+        from lens_amd.dist import shard_bounds
+        for b in shard_bounds(P, L, world)[1:-1]:
+            out[:, b - 2:b + 2] += rng.integers(20, 23, size=(17, 4)).astype(np.float32)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
@@ -70,6 +76,6 @@ def test_sharded_topk_allgather_merge(world, P, L, K):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1

@@ -42,6 +42,27 @@ def test_cli_matching_reproduces_reference_run(tag, argv):
     assert "Recall" in log and "Succesfully completed inferencing using LENS" in log
 
 
+@pytest.mark.parametrize("tag,argv", [("example", []), ("sunset", SUNSET)])
+def test_cli_recall_from_gpu_topk(tag, argv):
+    """`--amd_topk always`: Recall@N comes from the fused sequence matcher + top-25 on the GPU (what the CLI does by
+    itself for large databases).  It equals the reference's recallAtK under a stable sort -- the GPU path's explicit
+    tie policy -- and every listed place lies in the tie set of the reference's own (unstable) sort: its score is the
+    score the reference's ranking has at that rank."""
+    from lens_amd.metrics import recallAtK
+    G = np.load(os.path.join(GOLDEN, f"{tag}.npz"))
+    R, folder = _run(["--matching", "--amd_topk", "always"] + argv)
+    S, GT = G["S_carry"], G["GTtol"]
+    assert R == [round(recallAtK(S, GT, K=n, sort_kind="stable"), 2) for n in (1, 5, 10, 15, 20, 25)]
+    idx = np.load(os.path.join(folder, "topk_places.npy"))                  # [queries, 25], best first
+    assert idx.shape == (S.shape[1], 25)
+    ranked = -np.sort(-S, axis=0)[:25, :]                                   # scores by rank, per query column
+    assert np.array_equal(np.take_along_axis(S, idx.T.astype(np.int64), axis=0), ranked)
+    assert all(len(set(col)) == 25 for col in idx)                          # 25 different places per query
+    log = open(os.path.join(folder, "lens.log")).read()
+    assert "ties: higher score first, then the larger place index" in log
+    assert np.array_equal(np.load(os.path.join(folder, "similarity_matrix.npy")), S)   # `always` keeps the artefacts
+
+
 def test_cli_reset_state_variant():
     G = np.load(os.path.join(GOLDEN, "example.npz"))
     R, folder = _run(["--matching", "--amd_state", "reset"])

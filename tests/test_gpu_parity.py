@@ -359,18 +359,23 @@ def _encode_stream(steps, ev_scale, chunk=16):
     return np.array(ev, dtype=np.uint32).reshape(-1)
 
 
-@pytest.mark.parametrize("F", [2, 200, 400, 700])    # 4, 2, 1 places per lane, and the tile read through L2
-def test_stream_consumer_dropped_steps(O, F):
+# (F, P, places per LDS tile in batch mode): one case per generated assembly loop (64-, 128-, 192- and 256-place
+# tiles) and one for the C++ loop that reads the weights through L2; the tile width follows from (F, P)
+@pytest.mark.parametrize("F,P,tile", [(400, 5, 64), (200, 100, 128), (200, 150, 192), (100, 250, 256), (700, 5, 0)])
+def test_stream_consumer_dropped_steps(O, F, P, tile):
     """lens_output_counts on hand-built streams against the oracle's dense Linear + IAF, step by step.  The
     streams leave out the steps without spikes; the cases where such a step is not a no-op are all here:
     a membrane that the clip leaves at exactly 1.0 (weight 1 - 2^-24) fires in the first dropped step, an
-    empty step 0 on carried state, counts > 1 (mixed chunks) and >= 2^23 (no room for the flag bit)."""
+    empty step 0 on carried state, counts > 1 (mixed chunks) and >= 2^23 (no room for the flag bit).
+    Batch mode runs the tile width named by the case (asserted); carried state runs the width the library picks
+    for one wavefront per tile (the 64-place loop, or L2)."""
     import ctypes
+    from lens_amd import _lib
+    assert _lib.lib().lens_output_tile_places(F, P, 0, 0) == tile
     pred1 = float(np.nextafter(np.float32(1.0), np.float32(0.0)))
-    P = 5
-    w2 = np.zeros((P, F), dtype=np.float32)
-    w2[:, 0] = [pred1, 0.3, pred1, 0.45, 1e-7]    # a lone spike of feature 0 on rested membranes: nobody reaches 1.0,
-    w2[:, 1] = [-1.0, 0.2, pred1, 1.5, 1e-7]      # places 0 and 2 land on 1 - 2^-24, which the clip rounds up to 1.0
+    w2 = np.zeros((P, F), dtype=np.float32)       # the places beyond the first five stay silent
+    w2[:5, 0] = [pred1, 0.3, pred1, 0.45, 1e-7]   # a lone spike of feature 0 on rested membranes: nobody reaches 1.0,
+    w2[:5, 1] = [-1.0, 0.2, pred1, 1.5, 1e-7]     # places 0 and 2 land on 1 - 2^-24, which the clip rounds up to 1.0
     big = float(2 ** 23)
     queries = [
         [[], [(0, 1)], [], [(1, 1)], [], [], [(0, 1), (1, 2)], [], [(0, 1)], [], [(0, 3)], [(0, 1)], [(1, 1)], []],
@@ -386,21 +391,23 @@ def test_stream_consumer_dropped_steps(O, F):
     eng = _engine(w1, w2, 1, 1, T=max(T, 4))
     Q = len(queries)
     eng._workspace(Q)
-    words = np.zeros((Q, eng.cap), dtype=np.uint32)
-    nw = np.zeros(Q, dtype=np.int32)
-    for q, steps in enumerate(queries):
-        enc = _encode_stream(steps, eng.ev_scale)
-        words[q, :enc.size] = enc
-        nw[q] = enc.size
-    eng.events[:Q].copy_(torch.from_numpy(words.view(np.int32)))
-    eng.nwords[:Q].copy_(torch.from_numpy(nw))
     L = O.lib()
     fp = ctypes.POINTER(ctypes.c_float)
     ptr = lambda a: a.ctypes.data_as(fp)
     for carry in (False, True):
         eng.reset_state()
+        assert eng.tile_places(carry) == (tile if not carry else min(tile, 64))
+        words = np.zeros((Q, eng.cap), dtype=np.uint32)
+        nw = np.zeros(Q, dtype=np.int32)
+        for q, steps in enumerate(queries):
+            enc = _encode_stream(steps, eng.event_scale(carry))      # the row stride of this mode's tile
+            words[q, :enc.size] = enc
+            nw[q] = enc.size
+        eng.events[:Q].copy_(torch.from_numpy(words.view(np.int32)))
+        eng.nwords[:Q].copy_(torch.from_numpy(nw))
         if carry:   # a carried state that is not a clip output: step 0 may not be dropped
-            v0 = np.array([1.0, 2.5, -3.0, 0.99999994, 1e-30], dtype=np.float32)
+            v0 = np.zeros(P, dtype=np.float32)
+            v0[:5] = [1.0, 2.5, -3.0, 0.99999994, 1e-30]
             eng.v_out.copy_(torch.from_numpy(v0).cuda()[None, :])
         got = eng.output_counts(Q, carry=carry).cpu().numpy()
         v = v0.copy() if carry else None
@@ -417,7 +424,7 @@ def test_stream_consumer_dropped_steps(O, F):
                 L.lens_oracle_linear(ptr(x), ptr(w2), ptr(cur), F, P)
                 L.lens_oracle_iaf_step(ptr(v), ptr(cur), ptr(spk), P)
                 ref[q] += spk
-        assert np.array_equal(got, ref), (F, carry, got, ref)
+        assert np.array_equal(got, ref), (F, P, carry, got[:, :5], ref[:, :5])
         if carry:
             assert np.array_equal(eng.v_out.cpu().numpy()[0], v)
     assert ref[0, 0] != 0 or ref[3, 2] != 0

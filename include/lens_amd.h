@@ -40,6 +40,9 @@ extern "C" {
 
 #define LENS_AMD_ABI_VERSION 8
 
+/* Rows of slack behind the currents buffer of lens_feature_currents / lens_feature_fire. */
+#define LENS_FIRE_SLACK_ROWS 32
+
 /* Size of the library-owned device array behind lens_forward_counts_static (held once per GPU in use). */
 #define LENS_STATIC_SCRATCH_BYTES (64u << 20)
 
@@ -131,6 +134,41 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW,
                         float *d_vfeat, int n_streams, int carry,
                         uint32_t *d_events, int cap_words, uint32_t *d_nwords, int ev_scale,
                         float *d_featspk, void *stream);
+
+/*
+ * The feature layer for CARRIED state in two passes (same replacement as lens_feature_events with carry != 0, same
+ * streams bit for bit, several times faster for few streams): the reference never resets its IAF layers
+ * (lens/run_model.py:234-242), which makes a stream sequential in the query index -- but only the integrate-and-fire
+ * update is; the input current of a step depends on the frame alone.
+ *
+ * Pass 1, all queries in parallel.  Replaces lens/src/dataset.py:99-127 (raster), lens/run_model.py:130-137,141
+ * (centre-pixel Conv2d + IAF #1) and the Linear of :143:
+ *     d_currents[q][t][f] = ascending-n chain of fmaf(x[n], w1[f][n], acc) from +0,   float [Q][T][ldc],
+ *     ldc >= F and a multiple of 64 (columns F..ldc-1 are written as zeros).  N <= 1024, F <= 1024.
+ *     lens_feature_fire prefetches ahead: allocate LENS_FIRE_SLACK_ROWS more rows of ldc floats behind the last
+ *     query (never written, contents irrelevant).
+ */
+int lens_feature_currents(const uint8_t *d_frames, int Q, int HW, const int32_t *d_sel, int N,
+                          const uint8_t *d_codes, int T, const float *d_w1t, int F, int ldw1,
+                          float *d_currents, int ldc, void *stream);
+
+/* Bytes of the `d_scratch` argument of lens_feature_fire (per stream: the spike counts of the steps whose counts exceed 1). */
+size_t lens_feature_fire_scratch_bytes(int T, int F, int n_streams);
+
+/*
+ * Pass 2, one workgroup per carried stream, sequential in the query index.  Replaces the sinabs IAF #2 of
+ * lens/run_model.py:144 over the query loop :229-238: v += I; s = (v > 0) * trunc(v); v -= s; v = relu(v + 1) - 1,
+ * and writes the spike streams of lens_feature_events (same layout, same bits).
+ * d_vfeat [n_streams][F] carried state, read and written; queries are split into n_streams contiguous runs as in
+ * lens_feature_events.  d_scratch: lens_feature_fire_scratch_bytes(T, F, n_streams) bytes, 4-byte aligned, contents
+ * irrelevant.  d_currents: as written by lens_feature_currents, with its slack rows.  F <= 1024; T * ceil(F/64) * 24 bytes
+ * of tables must fit LDS (else LENS_ERR_UNSUPPORTED: use
+ * lens_feature_events).
+ */
+int lens_feature_fire(const float *d_currents, int ldc, int Q, int T, int F,
+                      float *d_vfeat, int n_streams,
+                      uint32_t *d_events, int cap_words, uint32_t *d_nwords, int ev_scale,
+                      void *d_scratch, void *stream);
 
 /*
  * Feature-spike streams -> output spike counts (rows of the similarity matrix).  Replaces

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("LENS_AMD_SO") or os.path.join(_PKG, "liblens_amd.so")
 SRC = os.path.join(_PKG, "csrc", "lens_kernels.hip")
 INCLUDES = [os.path.join(_PKG, "csrc", n)                            # textually included by SRC
-            for n in ("feature_loop_n2f4.inc", "output_loop_p1.inc", "output_loop_p2.inc", "output_loop_p3.inc",
+            for n in ("feature_loop_n2f4.inc", "fire_loop.inc", "output_loop_p1.inc", "output_loop_p2.inc", "output_loop_p3.inc",
                       "output_loop_p4.inc")]
 HEADER = os.path.join(ROOT, "include", "lens_amd.h")
 
@@ -40,6 +40,9 @@ SIGNATURES = {
     "lens_event_scale": (_i, [_i, _i, _i, _i]),
     "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
                                  _c_p, _i, _c_p, _i, _c_p, _c_p]),
+    "lens_feature_currents": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _c_p]),
+    "lens_feature_fire_scratch_bytes": (ctypes.c_size_t, [_i, _i, _i]),
+    "lens_feature_fire": (_i, [_c_p, _i, _i, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _c_p, _c_p]),
     "lens_output_counts": (_i, [_c_p, _i, _c_p, _i, _c_p, _i, _i, _i, _c_p, _i, _i, _i, _c_p, _i, _c_p]),
     "lens_forward_counts_static": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
                                         _c_p, _c_p, _i, _i, _i, _c_p, _i, _c_p]),

@@ -402,6 +402,270 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
 }
 
 // ------------------------------------------------------------------------------------------
+// a2-a5 for CARRIED state, in two passes.  The reference's query loop carries the membrane potentials from query
+// to query (lens/run_model.py:234-242), so the feature layer of one stream is a chain of Q x T dependent steps --
+// but only its integrate-and-fire update is: the input current of a step depends on the frame alone.
+//   pass 1  k_feature_currents  (all queries in parallel, one wavefront per query): raster + centre pixels +
+//           feature Linear -> I[q][t][f], the same ascending-n chain as k_feature_events;
+//   pass 2  k_feature_fire      (one workgroup per carried stream, sequential in the query index): wavefront w owns
+//           features [64w, 64w+64) -- they are independent of each other given I -- and walks the T steps without
+//           any synchronisation: one prefetched load, the IAF update on ONE register, and on a step in which its
+//           lanes fire the 64-bit spike mask into its row of an LDS table.  After the last step one barrier, then the
+//           workgroup expands the masks into the spike stream (thread = time step): per-step totals, a prefix sum
+//           for the positions, the LAST / EMPTY_NEXT / CHUNK_MIXED flags and explicit empty steps exactly as the
+//           one-pass writer of k_feature_events produces them (the streams are bit-identical).
+//           The currents buffer carries FIRE_DEPTH rows of slack behind its last query: the walk prefetches that far.
+// ------------------------------------------------------------------------------------------
+template <int NPL, int FPL, bool USE_LDS>
+__global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_currents(FeatArgs a, float *__restrict__ cur, int ldc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = NPL * 64, FP = FPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    uint8_t *s_codes = smem;
+    float *s_w = reinterpret_cast<float *>(smem + ((a.T * NP + 15) & ~15));
+    if constexpr (USE_LDS) {
+        for (int i = threadIdx.x; i < a.T * NP; i += blockDim.x) {
+            const int t = i / NP, n = i - t * NP;
+            s_codes[i] = (n < a.N) ? a.codes[(size_t)t * a.N + n] : (uint8_t)255;
+        }
+        for (int i = threadIdx.x; i < a.N * FP; i += blockDim.x) {
+            const int n = i / FP, f = i - n * FP;
+            s_w[i] = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+        }
+        __syncthreads();
+    }
+    const int q = blockIdx.x * nw + wave;
+    if (q >= a.Q) return;
+    uint32_t px[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = i * 64 + lane;
+        px[i] = (n < a.N) ? (uint32_t)a.frames[(size_t)q * a.HW + a.sel[n]] : 0u;
+    }
+    float *out = cur + (size_t)q * a.T * ldc;
+    for (int t = 0; t < a.T; ++t) {
+        float acc[FPL];
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            uint32_t code;
+            if constexpr (USE_LDS) {
+                code = s_codes[t * NP + i * 64 + lane];
+            } else {
+                const int n = i * 64 + lane;
+                code = (n < a.N) ? (uint32_t)a.codes[(size_t)t * a.N + n] : 255u;
+            }
+            uint64_t m = __ballot(px[i] >= code);
+            while (m) {   // active inputs in ascending n (wave-uniform loop)
+                const int n = i * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+#pragma unroll
+                for (int j = 0; j < FPL; ++j) {
+                    float w;
+                    if constexpr (USE_LDS) {
+                        w = s_w[n * FP + j * 64 + lane];
+                    } else {
+                        const int f = j * 64 + lane;
+                        w = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+                    }
+                    acc[j] = acc[j] + w;   // == fmaf(1.0f, w, acc): the input spike is exactly 1
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FPL; ++j)
+            if (j * 64 < ldc) out[(size_t)t * ldc + j * 64 + lane] = acc[j];
+    }
+}
+
+constexpr int FIRE_DEPTH = 32;         // steps whose currents are in flight per wavefront of k_feature_fire (fire_loop.inc)
+constexpr int FIRE_MAX_WAVES = 16;     // features <= 1024
+constexpr int FIRE_THREADS = 1024;     // workgroup of k_feature_fire: the walking wavefronts plus helpers for the merge
+static_assert(FIRE_DEPTH == LENS_FIRE_SLACK_ROWS, "the slack the header asks for is the walk's prefetch depth");
+
+struct FireArgs {
+    const float *cur; int ldc; int Q; int T; int F;
+    float *vfeat; int n_streams;
+    uint32_t *events; int cap; uint32_t *nwords; int ev_scale;
+    float *scratch;                     // [n_streams][2][NW][T][64] spike counts of the steps with a count above 1
+};
+
+// Inclusive prefix sum over the 64 lanes by DPP (no LDS crossbar): shifts within rows of 16 lanes, then the row totals
+// broadcast to the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xa, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xc, 0xf, true);
+    return x;
+}
+
+__global__ void __launch_bounds__(1024) k_feature_fire(FireArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // NW wavefronts walk (one per 64 features); the workgroup is launched with more (FIRE_THREADS) so that the merge,
+    // which is all latency, has several wavefronts per SIMD to hide it: the extra ones wait at the walk's barrier.
+    const int NW = (a.F + 63) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int T = a.T;
+    // per (wavefront, step): the 64-bit mask of the lanes that fired (0: no event) and a flag word (1: some count of the
+    // step is above 1; the 64 counts are then in the wavefront's scratch row of the step) -- two sets, used by
+    // alternate queries, so that a wavefront can start the next query while others still expand this one's masks;
+    // per step: its size in the stream (its events, or 1 for an explicit empty step) -> its position
+    const size_t set_bytes = ((size_t)NW * T * 12 + 7) & ~(size_t)7;
+    uint32_t *s_pos = reinterpret_cast<uint32_t *>(smem + 2 * set_bytes);      // [T + 1]
+    uint32_t *s_tot = s_pos + (T + 1);                                         // [T] events of the step
+    uint32_t *s_mixed = s_tot + T;                                             // bitmap over chunks: [(cap / 32 + 31) / 32]
+    const int mixed_words = (a.cap / EV_WORDS + 31) / 32;
+    uint32_t *s_any = s_mixed + mixed_words;                                   // some step needs the chunk-marking pass
+    const int s = blockIdx.x;
+    const int qs = (int)(((long long)s * a.Q) / a.n_streams);
+    const int qe = (int)(((long long)(s + 1) * a.Q) / a.n_streams);
+    const int f = w * 64 + lane;
+    float v = (f < a.F) ? a.vfeat[(size_t)s * a.F + f] : 0.0f;
+    const float *counts_sets = a.scratch + (size_t)s * 2 * NW * ((size_t)T * 64);   // [2][NW][T][64] spike counts of flagged steps
+    using lds_ptr = __attribute__((address_space(3))) unsigned char *;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
+    for (int q = qs; q < qe; ++q) {
+        const size_t set = (size_t)((q - qs) & 1) * set_bytes;
+        uint64_t *s_mask = reinterpret_cast<uint64_t *>(smem + set);                        // [NW][T]
+        uint32_t *s_flag = reinterpret_cast<uint32_t *>(smem + set + (size_t)NW * T * 8);   // [NW][T]
+        const float *counts_all = counts_sets + (size_t)((q - qs) & 1) * NW * ((size_t)T * 64);     // (alternating like the tables)
+        // ---------------- the T steps, every wavefront on its own (it touches only its own rows of the tables)
+        if (w < NW) {
+            for (int t = lane; t < T; t += 64) { s_mask[(size_t)w * T + t] = 0ull; s_flag[(size_t)w * T + t] = 0u; }
+            const float *row0 = a.cur + (size_t)q * T * a.ldc;              // wave-uniform
+            const float *sc = counts_all + (size_t)w * ((size_t)T * 64);
+            uint64_t hot = ~0ull;         // lanes whose membrane is exactly 1.0; all ones: step 0 always runs
+            uint32_t tab = lds0 + (uint32_t)(set + ((size_t)w * T) * 8);
+            uint32_t flg = lds0 + (uint32_t)(set + (size_t)NW * T * 8 + ((size_t)w * T) * 4);
+            // hand-scheduled gfx950 walk (scripts/gen_fire_loop.py): per step  v += I; fire test at 1 - 2^-24;
+            // s = floor(max(v, 0)); v -= s; v = clip(v)  -- the f32 operations of iaf_update_fast in its order
+            asm volatile(
+#include "fire_loop.inc"
+                : [v] "+&v"(v), [hot] "+&s"(hot), [tab] "+&v"(tab), [flg] "+&v"(flg)
+                : [ptr] "s"(row0), [sc] "s"(sc), [off] "v"((uint32_t)f * 4u), [lane4] "v"((uint32_t)lane * 4u),
+                  [ldc4] "s"((uint32_t)a.ldc * 4u), [T] "s"(T)
+                : "memory", "vcc", "scc",
+                  "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+                  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+                  "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+                  "v96", "v97", "v98", "v99");
+        }
+        // The (rare) count rows are read by the other wavefronts of this workgroup only: the walk ends with
+        // s_waitcnt vmcnt(0) (the stores have reached L2) and the readers load them past their L1 (agent-scope atomic
+        // loads), so the barrier's workgroup-scope fence is enough.  No wavefront is still in the previous query's
+        // merge once all have arrived here, so the per-step arrays below can be rewritten.
+        __syncthreads();
+        // ---------------- merge: thread = time step (in rounds of blockDim steps), then wave 0 scans the step sizes
+        auto count_bits = [&](int k, int t, int l) {   // count word of lane l's event of (wavefront k, step t)
+            if (!s_flag[(size_t)k * T + t]) return 0x3f800000u;
+            return __hip_atomic_load(reinterpret_cast<const uint32_t *>(counts_all) + ((size_t)k * T + t) * 64 + l,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto step_total = [&](int t) {
+            uint32_t n = 0;
+            for (int k = 0; k < NW; ++k) n += (uint32_t)__builtin_popcountll(s_mask[(size_t)k * T + t]);
+            return n;
+        };
+        auto step_big = [&](int t) {       // count of the step's last event >= 2^23 (the step has events)
+            for (int k = NW - 1; k >= 0; --k) {
+                const uint64_t m = s_mask[(size_t)k * T + t];
+                if (m) return count_bits(k, t, 63 - __builtin_clzll(m)) >= 0x4b000000u;
+            }
+            return false;
+        };
+        for (int i = threadIdx.x; i < mixed_words; i += blockDim.x) s_mixed[i] = 0u;
+        if (threadIdx.x == 0) *s_any = 0u;
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            const uint32_t tot = step_total(t);
+            // an empty step that must be written as the event {0, -0.0f}: step 0, or after a count >= 2^23
+            const bool expl = tot == 0 && (t == 0 || (step_total(t - 1) != 0 && step_big(t - 1)));
+            s_tot[t] = tot;
+            s_pos[t + 1] = tot + (expl ? 1u : 0u);
+            bool flagged = false;
+            if (tot) for (int k = 0; k < NW; ++k) flagged |= s_flag[(size_t)k * T + t] != 0;
+            if (expl && t == 0) atomicOr(&s_mixed[0], 1u);            // at position 0: chunk 0 holds a count that is not 1
+            else if (expl || flagged) *s_any = 1u;
+        }
+        __syncthreads();
+        if (w == 0) {                      // prefix sum of the step sizes, 64 steps per round
+            uint32_t carry = 0;
+            for (int b = 0; b < T; b += 64) {
+                const int t = b + lane;
+                const uint32_t inc = wave_inclusive_sum((t < T) ? s_pos[t + 1] : 0u);
+                if (t < T) s_pos[t + 1] = carry + inc;          // inclusive: position after step t
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+            if (lane == 0) s_pos[0] = 0u;
+        }
+        __syncthreads();
+        uint32_t *ev = a.events + (size_t)q * a.cap;
+        if (*s_any) {                      // (workgroup-uniform) chunks that hold a count other than 1: rare
+            for (int t = threadIdx.x; t < T; t += blockDim.x) {
+                uint32_t p = s_pos[t];
+                if (s_pos[t + 1] - p == 0) continue;
+                if (s_tot[t] == 0) { atomicOr(&s_mixed[(p >> 4) >> 5], 1u << ((p >> 4) & 31)); continue; }
+                for (int k = 0; k < NW; ++k) {
+                    const uint64_t m = s_mask[(size_t)k * T + t];
+                    if (s_flag[(size_t)k * T + t]) {
+                        uint32_t pe = p;
+                        for (uint64_t mm = m; mm; mm &= mm - 1, ++pe)
+                            if (count_bits(k, t, __builtin_ctzll(mm)) > 0x3f800000u) atomicOr(&s_mixed[(pe >> 4) >> 5], 1u << ((pe >> 4) & 31));
+                    }
+                    p += (uint32_t)__builtin_popcountll(m);
+                }
+            }
+            __syncthreads();
+        }
+        // one item per (step, walking wavefront): the events of that wavefront in that step, behind those of the lower ones
+        for (int i = threadIdx.x; i < T * NW; i += blockDim.x) {
+            const int t = i / NW, k = i - t * NW;
+            uint32_t p = s_pos[t];
+            if (s_pos[t + 1] - p == 0) continue;
+            // the step(s) that follow carry no spikes and are not written: flag on this step's LAST event
+            const bool empty_next = (t + 1 < T) && (s_pos[t + 2] - s_pos[t + 1] == 0);
+            auto put = [&](uint32_t pos, uint32_t w0, uint32_t w1) {
+                if ((pos & (EV_CHUNK - 1)) == 0 && ((s_mixed[(pos >> 4) >> 5] >> ((pos >> 4) & 31)) & 1u)) w0 |= EV_CHUNK_MIXED;
+                reinterpret_cast<uint2 *>(ev)[pos] = make_uint2(w0, w1);
+            };
+            const uint32_t tot = s_tot[t];
+            if (tot == 0) {                // explicit empty step
+                if (k == 0) put(p, 0u, EV_LAST | (empty_next ? EV_EMPTY_NEXT : 0u));
+                continue;
+            }
+            uint64_t m = s_mask[(size_t)k * T + t];
+            if (!m) continue;
+            const uint32_t last = p + tot - 1;
+            for (int j = 0; j < k; ++j) p += (uint32_t)__builtin_popcountll(s_mask[(size_t)j * T + t]);
+            const bool counted = s_flag[(size_t)k * T + t] != 0;      // counts above 1 in this (wavefront, step): rare
+            for (; m; m &= m - 1) {
+                const int l = __builtin_ctzll(m);
+                uint32_t w1 = counted ? count_bits(k, t, l) : 0x3f800000u;
+                if (p == last) w1 |= EV_LAST | ((empty_next && (w1 & 0x7fffffffu) < 0x4b000000u) ? EV_EMPTY_NEXT : 0u);
+                put(p, (uint32_t)(k * 64 + l) * (uint32_t)a.ev_scale, w1);
+                ++p;
+            }
+        }
+        const uint32_t count = s_pos[T];
+        const uint32_t pad = ((uint32_t)EV_CHUNK - (count & (EV_CHUNK - 1))) & (EV_CHUNK - 1);
+        if (threadIdx.x < pad) reinterpret_cast<uint2 *>(ev)[count + threadIdx.x] = make_uint2(0u, 0x3f800000u);
+        if (threadIdx.x == 0) a.nwords[q] = 2u * (count + pad);
+        // no barrier here: the next query's walk writes the other set of tables
+    }
+    if (f < a.F) a.vfeat[(size_t)s * a.F + f] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // a5-a6. spike streams -> output spike counts.
 //   A workgroup owns a tile of PT = 64*PPL places (their W2^T columns staged in LDS once) and a
 //   group of queries; each wavefront integrates whole queries against the tile, one lane =
@@ -1396,6 +1660,42 @@ int dispatch_feature_f(const FeatArgs &a, hipStream_t st)
     return launch_feature<NPL, 32>(a, st);
 }
 
+template <int NPL, int FPL>
+int launch_currents(const FeatArgs &a, float *cur, int ldc, hipStream_t st)
+{
+    constexpr int NP = NPL * 64, FP = FPL * 64;
+    const size_t lds = (((size_t)a.T * NP + 15) & ~(size_t)15) + (size_t)a.N * FP * 4;
+    const int wpb = feat_threads<NPL, FPL>() / 64;
+    const int blocks = (a.Q + wpb - 1) / wpb;
+    if (lds <= (size_t)LDS_BUDGET - 1024) {
+        auto k = k_feature_currents<NPL, FPL, true>;
+        if (int e = set_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(wpb * 64), lds, st, a, cur, ldc);
+    } else {
+        hipLaunchKernelGGL((k_feature_currents<NPL, FPL, false>), dim3(blocks), dim3(wpb * 64), 0, st, a, cur, ldc);
+    }
+    return (int)hipGetLastError();
+}
+
+template <int NPL>
+int dispatch_currents_f(const FeatArgs &a, float *cur, int ldc, hipStream_t st)
+{
+    const int fpl = (a.F + 63) / 64;
+    if (fpl <= 1) return launch_currents<NPL, 1>(a, cur, ldc, st);
+    if (fpl <= 2) return launch_currents<NPL, 2>(a, cur, ldc, st);
+    if (fpl <= 4) return launch_currents<NPL, 4>(a, cur, ldc, st);
+    if (fpl <= 8) return launch_currents<NPL, 8>(a, cur, ldc, st);
+    return launch_currents<NPL, 16>(a, cur, ldc, st);
+}
+
+// dynamic LDS of k_feature_fire: the per-step tables of one query (see the kernel)
+size_t fire_lds_bytes(int T, int F, int cap_words)
+{
+    const size_t NW = (size_t)(F + 63) / 64;
+    const size_t mixed_words = ((size_t)cap_words / EV_WORDS + 31) / 32;
+    return 2 * (((size_t)T * NW * 12 + 7) & ~(size_t)7) + (2 * (size_t)T + 1) * 4 + mixed_words * 4 + 16;
+}
+
 template <int PPL, bool W_LDS>
 int launch_output(const OutArgs &a, int threads, hipStream_t st)
 {
@@ -1588,6 +1888,53 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW, const int32_t *d
     if (npl <= 2) return dispatch_feature_f<2>(a, st);
     if (npl <= 4) return dispatch_feature_f<4>(a, st);
     return dispatch_feature_f<16>(a, st);
+}
+
+int lens_feature_currents(const uint8_t *d_frames, int Q, int HW, const int32_t *d_sel, int N,
+                          const uint8_t *d_codes, int T, const float *d_w1t, int F, int ldw1,
+                          float *d_currents, int ldc, void *stream)
+{
+    if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_currents) return LENS_ERR_NULL;
+    if (Q < 0 || HW <= 0 || N <= 0 || T <= 0 || F <= 0 || ldw1 < F) return LENS_ERR_SIZE;
+    if (ldc < F || (ldc & 63)) return LENS_ERR_SIZE;
+    if (N > 1024 || F > 64 * FIRE_MAX_WAVES) return LENS_ERR_UNSUPPORTED;
+    if (Q == 0) return LENS_OK;
+    FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, nullptr, Q, 0, nullptr, 0, nullptr, 1, nullptr};
+    hipStream_t st = (hipStream_t)stream;
+    const int npl = (N + 63) / 64;
+    if (npl <= 1) return dispatch_currents_f<1>(a, d_currents, ldc, st);
+    if (npl <= 2) return dispatch_currents_f<2>(a, d_currents, ldc, st);
+    if (npl <= 4) return dispatch_currents_f<4>(a, d_currents, ldc, st);
+    return dispatch_currents_f<16>(a, d_currents, ldc, st);
+}
+
+size_t lens_feature_fire_scratch_bytes(int T, int F, int n_streams)
+{
+    if (T <= 0 || F <= 0 || n_streams <= 0) return 0;
+    return (size_t)n_streams * 2 * ((size_t)(F + 63) / 64) * (size_t)T * 64 * sizeof(float);   // two sets, used by alternate queries
+}
+
+int lens_feature_fire(const float *d_currents, int ldc, int Q, int T, int F,
+                      float *d_vfeat, int n_streams,
+                      uint32_t *d_events, int cap_words, uint32_t *d_nwords, int ev_scale,
+                      void *d_scratch, void *stream)
+{
+    if (!d_currents || !d_vfeat || !d_events || !d_nwords || !d_scratch) return LENS_ERR_NULL;
+    if (Q < 0 || T <= 0 || F <= 0 || ldc < F || (ldc & 63)) return LENS_ERR_SIZE;
+    if ((size_t)cap_words < lens_event_capacity_words(T, F) || (cap_words & (EV_WORDS - 1))) return LENS_ERR_SIZE;
+    if (ev_scale < 1 || (long long)ev_scale * F > 0x7fffffffLL) return LENS_ERR_SIZE;
+    if (n_streams <= 0) n_streams = 1;
+    if (n_streams > Q && Q > 0) return LENS_ERR_SIZE;
+    if ((uintptr_t)d_scratch & 3) return LENS_ERR_ALIGN;
+    const int NW = (F + 63) / 64;
+    const size_t lds = fire_lds_bytes(T, F, cap_words);
+    if (NW > FIRE_MAX_WAVES || T >= (1 << 22) || lds > (size_t)LDS_BUDGET - 1024) return LENS_ERR_UNSUPPORTED;
+    if (Q == 0) return LENS_OK;
+    FireArgs a{d_currents, ldc, Q, T, F, d_vfeat, n_streams, d_events, cap_words, d_nwords, ev_scale,
+               static_cast<float *>(d_scratch)};
+    if (int e = set_lds(k_feature_fire, lds)) return e;
+    hipLaunchKernelGGL(k_feature_fire, dim3(n_streams), dim3(FIRE_THREADS), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
 }
 
 int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *d_nwords, int Q,

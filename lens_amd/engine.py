@@ -125,6 +125,13 @@ class LensEngine:
         self.n_streams = 1
         self.reset_state()
         self._ws_q = 0
+        # carried state: the two-pass feature layer (input currents of all queries in parallel, then the integrate-and-
+        # fire walk with one wavefront per 64 features) where its tables fit; else the one-wavefront kernel
+        self.ldc = (self.F + 63) // 64 * 64
+        self._cur = self._fire_scratch = None
+        nw = self.ldc // 64                                         # LDS tables of lens_feature_fire (its launch check)
+        tables = 2 * ((self.T * nw * 12 + 7) // 8 * 8) + (2 * self.T + 1) * 4 + ((self.cap // 32 + 31) // 32) * 4 + 16
+        self._two_pass = self.F <= 1024 and self.T < (1 << 22) and tables <= 159 * 1024
 
     # ---- state -------------------------------------------------------------------------
     def reset_state(self, n_streams=1):
@@ -146,6 +153,33 @@ class LensEngine:
     def ev_scale(self):
         return self.event_scale(False)
 
+    TWO_PASS_MAX_BYTES = 1 << 30     # largest currents tensor [Q][T][ldc] the carried path allocates
+
+    def _carried_two_pass(self, Q):
+        return self._two_pass and Q * self.T * self.ldc * 4 <= self.TWO_PASS_MAX_BYTES
+
+    def _carried_buffers(self, Q):
+        if self._cur is None or self._cur.shape[0] < Q:
+            # lens_feature_fire prefetches 32 rows ahead: that much slack behind the last query (one more query of rows)
+            self._cur_store = torch.empty(((Q + 1) * self.T + 32, self.ldc), dtype=torch.float32, device=self.device)
+            self._cur = self._cur_store[:Q * self.T].view(Q, self.T, self.ldc)
+        need = int(_lib.lib().lens_feature_fire_scratch_bytes(self.T, self.F, self.n_streams))
+        if self._fire_scratch is None or self._fire_scratch.numel() < need:
+            self._fire_scratch = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        return self._cur, self._fire_scratch
+
+    def _feature_currents(self, frames, cur):
+        st = _lib.lib().lens_feature_currents(
+            _ptr(frames), frames.shape[0], self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
+            _ptr(self.w1t), self.F, self.F, _ptr(cur), self.ldc, _stream())
+        _lib.check(st, "lens_feature_currents")
+
+    def _feature_fire(self, cur, Q, n_streams, events, nwords, scratch, scale):
+        st = _lib.lib().lens_feature_fire(
+            _ptr(cur), self.ldc, Q, self.T, self.F, _ptr(self.v_feat), n_streams,
+            _ptr(events), self.cap, _ptr(nwords), scale, _ptr(scratch), _stream())
+        _lib.check(st, "lens_feature_fire")
+
     def _workspace(self, Q):
         if Q > self._ws_q:
             self.events = torch.empty((Q, self.cap), dtype=torch.int32, device=self.device)
@@ -161,6 +195,11 @@ class LensEngine:
         Q = frames.shape[0]
         assert frames[0].numel() == self.HW, "frame size does not match roi_dim"
         self._workspace(Q)
+        if carry and not want_spikes and self._carried_two_pass(Q):
+            cur, scratch = self._carried_buffers(Q)
+            self._feature_currents(frames, cur)
+            self._feature_fire(cur, Q, self.n_streams, self.events, self.nwords, scratch, self.event_scale(True))
+            return None
         spk = torch.empty((Q, self.T, self.F), dtype=torch.float32, device=self.device) if want_spikes else None
         n_streams = self.n_streams if carry else 0
         st = _lib.lib().lens_feature_events(
@@ -236,18 +275,27 @@ class LensEngine:
         # frees and re-allocations ordered on the main stream (reset_state, a larger workspace) come after the side
         # stream's work.  An event of the pair is re-recorded two chunks later, after the main stream's wait on it
         # was enqueued (a wait refers to the record that preceded it).
+        two_pass = self._carried_two_pass(Q)
+        if two_pass:
+            cur, scratch = self._carried_buffers(Q)      # allocated on the main stream, before the side stream waits for it
         side.wait_stream(main)          # frames are ready, and earlier readers of the workspace have finished
         try:
+            if two_pass:                # the input currents of the whole call, in parallel, ahead of the sequential walk
+                with torch.cuda.stream(side):
+                    self._feature_currents(frames, cur)
             for k, c0 in enumerate(range(0, Q, self.CARRY_CHUNK)):
                 c1 = min(Q, c0 + self.CARRY_CHUNK)
                 fr, ev, nw = frames[c0:c1], self.events[c0:c1], self.nwords[c0:c1]
                 done = self._side_done[k & 1]
                 with torch.cuda.stream(side):
-                    st = L.lens_feature_events(
-                        _ptr(fr), c1 - c0, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
-                        _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), 1, 1,
-                        _ptr(ev), self.cap, _ptr(nw), scale, None, _stream())
-                    _lib.check(st, "lens_feature_events")
+                    if two_pass:
+                        self._feature_fire(cur[c0:c1], c1 - c0, 1, ev, nw, scratch, scale)
+                    else:
+                        st = L.lens_feature_events(
+                            _ptr(fr), c1 - c0, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
+                            _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), 1, 1,
+                            _ptr(ev), self.cap, _ptr(nw), scale, None, _stream())
+                        _lib.check(st, "lens_feature_events")
                     done.record(side)
                 main.wait_event(done)
                 o = out[c0:c1]

@@ -473,3 +473,58 @@ def test_batch_pipeline_equals_single_stream(O):
     assert np.array_equal(counts[2].cpu().numpy(),
                           O.forward(batches[2].cpu().numpy(), 10, O.rand_U(250, 128 * 128), np.asarray(w1, np.float32),
                                     w2.numpy(), carry=False, skip_zero=True))
+
+
+def test_two_pass_carried_feature_layer_writes_identical_streams(O):
+    """Carried state: lens_feature_currents + lens_feature_fire (input currents of all queries in parallel, then the
+    integrate-and-fire walk with one wavefront per 64 features and a merge of their event lists) against the
+    one-wavefront lens_feature_events: the same words in every stream (flags, explicit empty steps, padding), the
+    same lengths and the same carried membranes -- on the bundled sets and on shapes that exercise counts above 1,
+    silent steps, a ragged last wavefront, T not a multiple of the prefetch depth and several streams."""
+    from lens_amd import _lib
+    from lens_amd.engine import _ptr, _stream
+    rng = np.random.default_rng(77)
+    cases = []
+    for tag in ("example", "sunset"):
+        c, frames, w1, w2, gt, G = load_config(tag)
+        cases.append((w1, w2[:64], c["roi"], c["dims"], 250, frames[:40], 1))
+    for dims, roi, F, T, dens, wscale, streams in [(5, 10, 157, 33, 255, 0.8, 1), (8, 16, 313, 250, 40, 0.3, 3),
+                                                   (3, 9, 40, 7, 255, 3.0, 1), (10, 20, 1024, 19, 90, 0.5, 2),
+                                                   (6, 12, 64, 64, 2, 0.9, 1), (4, 8, 65, 100, 255, 1e9, 1)]:
+        N = dims * dims
+        w1 = (rng.standard_normal((F, N)) * wscale).astype(np.float32)
+        w1[rng.random((F, N)) < 0.3] = 0
+        w2 = (rng.standard_normal((8, F)) * 0.1).astype(np.float32)
+        frames = rng.integers(0, dens + 1, size=(11, roi, roi)).astype(np.uint8)
+        frames[3] = 0
+        cases.append((w1, w2, roi, dims, T, frames, streams))
+    L = _lib.lib()
+    for w1, w2, roi, dims, T, frames, streams in cases:
+        eng = _engine(w1, w2, roi, dims, T=T)
+        assert eng._two_pass
+        fr = torch.from_numpy(frames).cuda()
+        Q = fr.shape[0]
+        got = []
+        for two_pass in (False, True):
+            eng.reset_state(streams)
+            eng.v_feat.copy_(torch.linspace(-0.9, 0.99, eng.v_feat.numel(), device="cuda").view_as(eng.v_feat))
+            eng._workspace(Q)
+            eng.events.fill_(-1); eng.nwords.fill_(-1)
+            for rep in range(2):                                 # the second call starts from the first one's state
+                if two_pass:
+                    eng.feature_events(fr, carry=True)
+                else:
+                    st = L.lens_feature_events(_ptr(fr), Q, eng.HW, _ptr(eng.sel), eng.N, _ptr(eng.codes), eng.T, _ptr(eng.w1t),
+                                               eng.F, eng.F, _ptr(eng.v_feat), streams, 1, _ptr(eng.events), eng.cap,
+                                               _ptr(eng.nwords), eng.event_scale(True), None, _stream())
+                    assert st == 0
+            torch.cuda.synchronize()
+            nw = eng.nwords[:Q].cpu().numpy()
+            ev = eng.events[:Q].cpu().numpy()
+            got.append((nw, [ev[q, :nw[q]].copy() for q in range(Q)], eng.v_feat.cpu().numpy().copy()))
+        (nw0, ev0, v0), (nw1, ev1, v1) = got
+        assert np.array_equal(nw0, nw1), (w1.shape, T, nw0, nw1)
+        for q in range(Q):
+            assert np.array_equal(ev0[q], ev1[q]), (w1.shape, T, q)
+        assert np.array_equal(v0, v1)
+        assert nw0.max() > 32 or w1.shape[0] == 64

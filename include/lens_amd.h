@@ -87,6 +87,14 @@ int lens_accumulate_events(const int16_t *d_xy, const int64_t *d_frame_off, int 
  */
 int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_codes);
 
+/*
+ * HOST helper: for every input neuron n and pixel value p, the number of time steps in which n spikes,
+ *     h_active_steps[n][p] = #{ t : h_codes[t][n] <= p },        uint16 [N][256], T <= 65535.
+ * The sum over a frame's selected pixels is the exact number of input spikes of that query: the optional load-balancing
+ * hint of lens_feature_events.  (No counterpart in the reference, whose loop handles one query at a time.)
+ */
+int lens_build_active_steps(const uint8_t *h_codes, int T, int N, uint16_t *h_active_steps);
+
 /* Words of `events` a query needs in the worst case: 2 * T * max(F, 1) rounded up to whole 32-word chunks. */
 size_t lens_event_capacity_words(int T, int F);
 
@@ -125,6 +133,9 @@ int lens_event_scale(int F, int P, int carry, int n_groups);
  *   a step without spikes that cannot be dropped that way (step 0, or after a count >= 2^23) is the event
  *   {0, -0.0f}; {0, +1.0f} pads to a multiple of 32 words.  Dropping is exact: see lens_kernels.hip.
  * d_featspk (optional, NULL to skip): float [Q][T][F] dense spike counts.
+ * d_active_steps (optional, NULL to skip): the table of lens_build_active_steps on the device.  With it, in batch mode
+ *        (carry == 0, one stream per query) the 16 queries of a workgroup are dealt to its wavefronts by their number of
+ *        input spikes so that the CU's four SIMDs finish together; results do not depend on it.
  * Limits: N <= 1024, F <= 2048, cap_words >= lens_event_capacity_words(T, F), ev_scale * F < 2^31.
  */
 int lens_feature_events(const uint8_t *d_frames, int Q, int HW,
@@ -133,7 +144,7 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW,
                         const float *d_w1t, int F, int ldw1,
                         float *d_vfeat, int n_streams, int carry,
                         uint32_t *d_events, int cap_words, uint32_t *d_nwords, int ev_scale,
-                        float *d_featspk, void *stream);
+                        float *d_featspk, const uint16_t *d_active_steps, void *stream);
 
 /*
  * The feature layer for CARRIED state in two passes (same replacement as lens_feature_events with carry != 0, same

@@ -38,8 +38,9 @@ SIGNATURES = {
     "lens_event_capacity_words": (ctypes.c_size_t, [_i, _i]),
     "lens_output_tile_places": (_i, [_i, _i, _i, _i]),
     "lens_event_scale": (_i, [_i, _i, _i, _i]),
+    "lens_build_active_steps": (_i, [_c_p, _i, _i, _c_p]),
     "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
-                                 _c_p, _i, _c_p, _i, _c_p, _c_p]),
+                                 _c_p, _i, _c_p, _i, _c_p, _c_p, _c_p]),
     "lens_feature_currents": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _c_p]),
     "lens_feature_fire_scratch_bytes": (ctypes.c_size_t, [_i, _i, _i]),
     "lens_feature_fire": (_i, [_c_p, _i, _i, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _c_p, _c_p]),

@@ -178,6 +178,7 @@ struct FeatArgs {
     float *vfeat; int n_streams; int carry;
     uint32_t *events; int cap; uint32_t *nwords; int ev_scale;
     float *featspk;
+    const uint16_t *active_steps;   // [N][256]: steps in which input n spikes for pixel value p (optional: load balance)
 };
 
 // Wavefronts per workgroup: the staged tables allow one workgroup per CU, so the workgroup is as
@@ -225,9 +226,41 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
                 s_w[i] = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
             }
         }
-        __syncthreads();
     }
-    const int s = blockIdx.x * nw + wave;
+    int s = blockIdx.x * nw + wave;
+    // Batch mode, one query per wavefront: the queries of the workgroup are dealt to its wavefronts by their work (the
+    // number of input spikes, exact from the table), heaviest and lightest together, so that the four SIMDs of the CU --
+    // wavefront w runs on SIMD w % 4 -- get about the same sum; the kernel's time is the slowest SIMD's.
+    const bool deal = USE_LDS && a.active_steps && !a.carry && a.n_streams == a.Q && nw == 16 && !a.featspk;
+    uint32_t *s_est = reinterpret_cast<uint32_t *>(smem + (((a.T * NP + 15) & ~15) + (size_t)a.N * FP * 4));   // behind the tables
+    if (deal) {
+        uint32_t e = 0;
+        if (s < a.Q) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int n = i * 64 + lane;
+                if (n < a.N) e += a.active_steps[n * 256 + a.frames[(size_t)s * a.HW + a.sel[n]]];
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) e += (uint32_t)__shfl_xor((int)e, d, 64);
+        if (lane == 0) s_est[wave] = e;
+    }
+    if constexpr (USE_LDS) __syncthreads();
+    if (deal) {
+        // lane j < 16 ranks wavefront j (heaviest = 0, ties by index); sorted position of my slot: SIMD g = w % 4, round
+        // k = w / 4, the rounds alternate direction; I take the query of the wavefront that holds that rank
+        const uint32_t mine = s_est[lane & 15];
+        int r = 0;
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t other = s_est[j];
+            r += (other > mine || (other == mine && j < (lane & 15))) ? 1 : 0;
+        }
+        const int g = wave & 3, k = wave >> 2;
+        const int want = 4 * k + ((k & 1) ? 3 - g : g);
+        const uint64_t hit = __ballot(lane < 16 && r == want);
+        s = blockIdx.x * nw + __builtin_ctzll(hit);
+    }
     if (s >= a.n_streams) return;
     const int qs = (int)(((long long)s * a.Q) / a.n_streams);
     const int qe = (int)(((long long)(s + 1) * a.Q) / a.n_streams);
@@ -678,6 +711,8 @@ struct OutArgs {
     float *vout; int ldv; int n_groups; int carry;
     float *counts; int ldo;
     int ntiles;
+    int Qv;          // queries per tile in the list of (tile, query) pairs (Q, or Q padded to whole groups of an explicit split)
+    long long W;     // batch mode: pairs per workgroup
 };
 
 template <int PPL> struct VecT;
@@ -869,135 +904,161 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
     constexpr int PT = 64 * PPL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = blockIdx.x % a.ntiles;
-    const int grp = blockIdx.x / a.ntiles;
-    const int p0 = tile * PT;
 
-    // Queries of the group are handed to the wavefronts first come, first served: stream lengths vary by +-20 %
-    // (std) between queries, and with a fixed assignment the slowest of the 16 wavefronts sets the pace (+14 %
-    // on average, +26 % for the slowest workgroup at P=1000).
-    // The kernel owns no static LDS: the tile starts at LDS address 0 (the assembly loop of the 192-place tile relies
-    // on it, launch_output checks it) and the bookkeeping sits behind the tile in the same dynamic block.
+    // Work = all (tile, query) pairs, tile-major.  Carried state: workgroup = (tile, stream), ONE wavefront, which walks
+    // the stream's queries in order.  Batch mode: workgroup b owns the pairs [b * W, (b + 1) * W) -- a run of queries of
+    // one tile, then of the next ones -- so a tile is staged once per run, not once per (tile, query group), and the
+    // 16 wavefronts pull the queries of a run first come, first served (stream lengths vary by +-20 % (std) between
+    // queries; with a fixed assignment the slowest wavefront sets the pace): they idle only at the end of a run, a
+    // few times per launch.  The kernel owns no static LDS: the tile starts at LDS address 0 (the assembly loop of the
+    // 192-place tile relies on it, launch_output checks it) and the bookkeeping sits behind the tile in the same block.
     unsigned char *book = smem + (W_LDS ? (size_t)a.F * PT * 4 : 0);
     uint32_t *s_len = reinterpret_cast<uint32_t *>(book);                              // [OUT_ORDER_MAX]
-    uint16_t *s_order = reinterpret_cast<uint16_t *>(book + OUT_ORDER_MAX * 4);          // longest stream first (when the group is small enough to rank)
+    uint16_t *s_order = reinterpret_cast<uint16_t *>(book + OUT_ORDER_MAX * 4);          // longest stream first (when the run is small enough to rank)
     int &s_next = *reinterpret_cast<int *>(book + (a.carry ? 0 : OUT_ORDER_MAX * 6));   // carried state: the book is this word only
-    if (threadIdx.x == 0) s_next = 0;
-    if constexpr (W_LDS) {
-        float4 *dst = reinterpret_cast<float4 *>(smem);
-        const int n4 = a.F * (PT / 4);
-        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-            const int f = i / (PT / 4), c = i - f * (PT / 4);
-            if constexpr (PPL == 3) {
-                // a 192-place tile may reach past the padded row (ldw is a multiple of 256, not of 192)
-                float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (p0 + c * 4 < a.ldw) x = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
-                // places 0..127 of the row -> pairs plane (behind the F x 256 bytes of the thirds plane), 128..191 -> thirds
-                unsigned char *d = c < 32 ? smem + (size_t)a.F * 256 + (size_t)f * 512 + c * 16 : smem + (size_t)f * 256 + (c - 32) * 16;
-                *reinterpret_cast<float4 *>(d) = x;
-            } else {
-                dst[i] = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
-            }
-        }
-    }
-    const int qs = (int)(((long long)grp * a.Q) / a.n_groups);
-    const int qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
-    const int nq = qe - qs;
-    // Longest first pays when the whole grid is one or two rounds of workgroups (the tail of the slowest one is the
-    // kernel's tail); with many rounds the dispatcher evens things out and the O(nq^2) ranking is a net loss.
-    const bool ranked = !a.carry && nq <= OUT_ORDER_MAX && gridDim.x <= 512;
-    if (ranked) {
-        for (int t = threadIdx.x; t < nq; t += blockDim.x) s_len[t] = a.nwords[qs + t];
-    }
-    __syncthreads();
-    if (ranked) {   // rank by counting: position of query t = number of queries that come before it
-        for (int t = threadIdx.x; t < nq; t += blockDim.x) {
-            const uint32_t mine = s_len[t];
-            int r = 0;
-            for (int j = 0; j < nq; ++j) {
-                const uint32_t other = s_len[j];
-                r += (other > mine || (other == mine && j < t)) ? 1 : 0;
-            }
-            s_order[r] = (uint16_t)t;
-        }
-        __syncthreads();
-    }
-    const int pl = p0 + lane * PPL;   // first place of this lane (contiguous layouts)
-    int place[PPL];
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) place[k] = p0 + lane_place<PPL>(lane, k);
 
-    float v[PPL], cnt[PPL], acc[PPL];
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) v[k] = 0.0f;
+    long long lo, hi;                        // this workgroup's pairs, in units of Qv (virtual queries per tile) per tile
+    int grp = 0;
     if (a.carry) {
-        if (wave != 0) return;   // a carried stream is sequential: one wavefront per tile
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) v[k] = (place[k] < a.P) ? a.vout[(size_t)grp * a.ldv + place[k]] : 0.0f;
+        const int tile = blockIdx.x % a.ntiles;
+        grp = blockIdx.x / a.ntiles;
+        lo = (long long)tile * a.Qv + (int)(((long long)grp * a.Q) / a.n_groups);
+        hi = (long long)tile * a.Qv + (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
+        if (wave != 0) return;               // a carried stream is sequential: one wavefront per tile
+    } else {
+        lo = (long long)blockIdx.x * a.W;
+        hi = lo + a.W;
+        const long long all = (long long)a.ntiles * a.Qv;
+        if (hi > all) hi = all;
     }
     const uint32_t lane_off = (uint32_t)lane * (PPL == 3 ? 8 : PPL * 4);
-    for (int it = 0;; ++it) {
-        int q = qs + it;                       // carry: the one wavefront walks the group in order
-        if (!a.carry) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&s_next, 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= nq) break;
-            q = qs + (ranked ? (int)s_order[t] : t);
-        }
-        if (q >= qe) break;
-        q = __builtin_amdgcn_readfirstlane(q);   // wave-uniform by construction; the stream pointer must live in SGPRs
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) {
-            if (!a.carry) v[k] = 0.0f;
-            cnt[k] = 0.0f;
-            acc[k] = 0.0f;
-        }
-        const uint32_t *ev = a.events + (size_t)q * a.cap;
+    bool first_run = true;
+    while (lo < hi) {
+        const int tile = (int)(lo / a.Qv);
+        const int qs = (int)(lo - (long long)tile * a.Qv);
+        long long run = (long long)a.Qv - qs;
+        if (run > hi - lo) run = hi - lo;
+        lo += run;
+        int qe = qs + (int)run;
+        if (qe > a.Q) qe = a.Q;              // (virtual queries beyond Q pad the last group of an explicit split)
+        const int nq = qe - qs;
+        if (nq <= 0) continue;
+        const int p0 = tile * PT;
+        if (!first_run) __syncthreads();     // every wavefront has finished with the previous tile
+        first_run = false;
+        if (threadIdx.x == 0) s_next = 0;
         if constexpr (W_LDS) {
-            using lds_ptr = __attribute__((address_space(3))) unsigned char *;
-            const uint32_t lane_addr = (uint32_t)(uintptr_t)(lds_ptr)smem + lane_off + (PPL == 3 ? (uint32_t)a.F * 256u : 0u);
-            output_loop_asm<PPL>(ev, a.nwords + q, lane_addr, v, cnt);
-        } else {
-            const int nch = __builtin_amdgcn_readfirstlane((int)(a.nwords[q] / EV_WORDS));
-            // One chunk (EV_CHUNK events) per scalar prefetch, two SGPR buffers in ping-pong.  Per chunk: weight
-            // reads -> lgkmcnt(0) -> scalar load of the next chunk -> VALU/SALU-only integration while it is in flight.
-            uint32_t ea[EV_WORDS], eb[EV_WORDS];
-            float w[EV_CHUNK][PPL];
-#pragma unroll
-            for (int i = 0; i < EV_WORDS; ++i) ea[i] = ev[i];
-            const char *p = reinterpret_cast<const char *>(ev);   // chunk being integrated (byte pointer: the token adds unshifted)
-            for (int c = 0; c < nch; c += 2) {
-                load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, w);
-                p += EV_WORDS * 4;
-                const uint32_t *nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
-                if (c + 1 < nch) {
-#pragma unroll
-                    for (int i = 0; i < EV_WORDS; ++i) eb[i] = nxt[i];
+            float4 *dst = reinterpret_cast<float4 *>(smem);
+            const int n4 = a.F * (PT / 4);
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+                const int f = i / (PT / 4), c = i - f * (PT / 4);
+                if constexpr (PPL == 3) {
+                    // a 192-place tile may reach past the padded row (ldw is a multiple of 256, not of 192)
+                    float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (p0 + c * 4 < a.ldw) x = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
+                    // places 0..127 of the row -> pairs plane (behind the F x 256 bytes of the thirds plane), 128..191 -> thirds
+                    unsigned char *d = c < 32 ? smem + (size_t)a.F * 256 + (size_t)f * 512 + c * 16 : smem + (size_t)f * 256 + (c - 32) * 16;
+                    *reinterpret_cast<float4 *>(d) = x;
+                } else {
+                    dst[i] = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
                 }
-                if (ea[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(ea, w, v, cnt, acc);
-                else integrate_chunk<PPL, true>(ea, w, v, cnt, acc);
-                if (c + 1 >= nch) break;
-                load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
-                p += EV_WORDS * 4;
-                nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
-                if (c + 2 < nch) {
-#pragma unroll
-                    for (int i = 0; i < EV_WORDS; ++i) ea[i] = nxt[i];
-                }
-                if (eb[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(eb, w, v, cnt, acc);
-                else integrate_chunk<PPL, true>(eb, w, v, cnt, acc);
             }
         }
-        float *o = a.counts + (size_t)q * a.ldo;
+        // Longest first pays when the whole grid is one or two rounds of short runs (the tail of the slowest workgroup
+        // is the kernel's tail); in a long run the first-come-first-served hand-out evens things out by itself and the
+        // O(nq^2) ranking would be a net loss.
+        const bool ranked = !a.carry && nq <= OUT_ORDER_MAX && gridDim.x <= 512;
+        if (ranked) {
+            for (int t = threadIdx.x; t < nq; t += blockDim.x) s_len[t] = a.nwords[qs + t];
+        }
+        __syncthreads();
+        if (ranked) {   // rank by counting: position of query t = number of queries that come before it
+            for (int t = threadIdx.x; t < nq; t += blockDim.x) {
+                const uint32_t mine = s_len[t];
+                int r = 0;
+                for (int j = 0; j < nq; ++j) {
+                    const uint32_t other = s_len[j];
+                    r += (other > mine || (other == mine && j < t)) ? 1 : 0;
+                }
+                s_order[r] = (uint16_t)t;
+            }
+            __syncthreads();
+        }
+        const int pl = p0 + lane * PPL;   // first place of this lane (contiguous layouts)
+        int place[PPL];
 #pragma unroll
-        for (int k = 0; k < PPL; ++k)
-            if (place[k] < a.P) o[place[k]] = cnt[k];
-    }
-    if (a.carry) {
+        for (int k = 0; k < PPL; ++k) place[k] = p0 + lane_place<PPL>(lane, k);
+
+        float v[PPL], cnt[PPL], acc[PPL];
 #pragma unroll
-        for (int k = 0; k < PPL; ++k)
-            if (place[k] < a.P) a.vout[(size_t)grp * a.ldv + place[k]] = v[k];
+        for (int k = 0; k < PPL; ++k) v[k] = 0.0f;
+        if (a.carry) {
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) v[k] = (place[k] < a.P) ? a.vout[(size_t)grp * a.ldv + place[k]] : 0.0f;
+        }
+        for (int it = 0;; ++it) {
+            int q = qs + it;                       // carry: the one wavefront walks the run in order
+            if (!a.carry) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&s_next, 1);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= nq) break;
+                q = qs + (ranked ? (int)s_order[t] : t);
+            }
+            if (q >= qe) break;
+            q = __builtin_amdgcn_readfirstlane(q);   // wave-uniform by construction; the stream pointer must live in SGPRs
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                if (!a.carry) v[k] = 0.0f;
+                cnt[k] = 0.0f;
+                acc[k] = 0.0f;
+            }
+            const uint32_t *ev = a.events + (size_t)q * a.cap;
+            if constexpr (W_LDS) {
+                using lds_ptr = __attribute__((address_space(3))) unsigned char *;
+                const uint32_t lane_addr = (uint32_t)(uintptr_t)(lds_ptr)smem + lane_off + (PPL == 3 ? (uint32_t)a.F * 256u : 0u);
+                output_loop_asm<PPL>(ev, a.nwords + q, lane_addr, v, cnt);
+            } else {
+                const int nch = __builtin_amdgcn_readfirstlane((int)(a.nwords[q] / EV_WORDS));
+                // One chunk (EV_CHUNK events) per scalar prefetch, two SGPR buffers in ping-pong.  Per chunk: weight
+                // reads -> lgkmcnt(0) -> scalar load of the next chunk -> VALU/SALU-only integration while it is in flight.
+                uint32_t ea[EV_WORDS], eb[EV_WORDS];
+                float w[EV_CHUNK][PPL];
+#pragma unroll
+                for (int i = 0; i < EV_WORDS; ++i) ea[i] = ev[i];
+                const char *p = reinterpret_cast<const char *>(ev);   // chunk being integrated (byte pointer: the token adds unshifted)
+                for (int c = 0; c < nch; c += 2) {
+                    load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, w);
+                    p += EV_WORDS * 4;
+                    const uint32_t *nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
+                    if (c + 1 < nch) {
+#pragma unroll
+                        for (int i = 0; i < EV_WORDS; ++i) eb[i] = nxt[i];
+                    }
+                    if (ea[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(ea, w, v, cnt, acc);
+                    else integrate_chunk<PPL, true>(ea, w, v, cnt, acc);
+                    if (c + 1 >= nch) break;
+                    load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
+                    p += EV_WORDS * 4;
+                    nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
+                    if (c + 2 < nch) {
+#pragma unroll
+                        for (int i = 0; i < EV_WORDS; ++i) ea[i] = nxt[i];
+                    }
+                    if (eb[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(eb, w, v, cnt, acc);
+                    else integrate_chunk<PPL, true>(eb, w, v, cnt, acc);
+                }
+            }
+            float *o = a.counts + (size_t)q * a.ldo;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k)
+                if (place[k] < a.P) o[place[k]] = cnt[k];
+        }
+        if (a.carry) {
+#pragma unroll
+            for (int k = 0; k < PPL; ++k)
+                if (place[k] < a.P) a.vout[(size_t)grp * a.ldv + place[k]] = v[k];
+        }
     }
 }
 
@@ -1625,7 +1686,7 @@ template <int NPL, int FPL>
 int launch_feature(const FeatArgs &a, hipStream_t st)
 {
     constexpr int NP = NPL * 64, FP = FPL * 64;
-    const size_t lds = (((size_t)a.T * NP + 15) & ~(size_t)15) + (size_t)a.N * FP * 4;
+    const size_t lds = (((size_t)a.T * NP + 15) & ~(size_t)15) + (size_t)a.N * FP * 4 + 64;   // tables + 16 work estimates
     const int wpb = feat_threads<NPL, FPL>() / 64;   // wavefronts per workgroup sharing the staged tables
     const int blocks = (a.n_streams + wpb - 1) / wpb;
     if (lds <= (size_t)LDS_BUDGET - 1024) {
@@ -1697,7 +1758,7 @@ size_t fire_lds_bytes(int T, int F, int cap_words)
 }
 
 template <int PPL, bool W_LDS>
-int launch_output(const OutArgs &a, int threads, hipStream_t st)
+int launch_output(const OutArgs &a, int threads, int grid, hipStream_t st)
 {
     // carried state: one wavefront per workgroup, no query ranking -- only the (unused) counter word behind the tile,
     // so that three 50 KB tiles still fit one CU
@@ -1715,7 +1776,7 @@ int launch_output(const OutArgs &a, int threads, hipStream_t st)
         }
     }
     if (int e = set_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)(a.ntiles * a.n_groups)), dim3(threads), lds, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -1807,6 +1868,22 @@ int lens_build_threshold_codes(const float *h_u_sel, int T, int N, uint8_t *h_co
     return LENS_OK;
 }
 
+int lens_build_active_steps(const uint8_t *h_codes, int T, int N, uint16_t *h_active_steps)
+{
+    if (!h_codes || !h_active_steps) return LENS_ERR_NULL;
+    if (T < 0 || T > 65535 || N < 0) return LENS_ERR_SIZE;
+    for (int n = 0; n < N; ++n) {
+        uint32_t hist[256] = {0};
+        for (int t = 0; t < T; ++t) hist[h_codes[(size_t)t * N + n]]++;
+        uint32_t run = 0;
+        for (int p = 0; p < 256; ++p) {             // input n spikes at step t iff px >= code[t][n]
+            run += hist[p];
+            h_active_steps[(size_t)n * 256 + p] = (uint16_t)run;
+        }
+    }
+    return LENS_OK;
+}
+
 size_t lens_event_capacity_words(int T, int F)
 {
     const size_t per_step = (size_t)(F > 1 ? F : 1);   // events per step, 2 words each
@@ -1867,7 +1944,7 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW, const int32_t *d
                         const uint8_t *d_codes, int T, const float *d_w1t, int F, int ldw1,
                         float *d_vfeat, int n_streams, int carry,
                         uint32_t *d_events, int cap_words, uint32_t *d_nwords, int ev_scale,
-                        float *d_featspk, void *stream)
+                        float *d_featspk, const uint16_t *d_active_steps, void *stream)
 {
     if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_events || !d_nwords) return LENS_ERR_NULL;
     if (carry && !d_vfeat) return LENS_ERR_NULL;
@@ -1881,7 +1958,7 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW, const int32_t *d
         n_streams = carry ? 1 : Q;
     }
     FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, d_vfeat, n_streams, carry ? 1 : 0,
-               d_events, cap_words, d_nwords, ev_scale, d_featspk};
+               d_events, cap_words, d_nwords, ev_scale, d_featspk, d_active_steps};
     hipStream_t st = (hipStream_t)stream;
     const int npl = (N + 63) / 64;
     if (npl <= 1) return dispatch_feature_f<1>(a, st);
@@ -1899,7 +1976,7 @@ int lens_feature_currents(const uint8_t *d_frames, int Q, int HW, const int32_t 
     if (ldc < F || (ldc & 63)) return LENS_ERR_SIZE;
     if (N > 1024 || F > 64 * FIRE_MAX_WAVES) return LENS_ERR_UNSUPPORTED;
     if (Q == 0) return LENS_OK;
-    FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, nullptr, Q, 0, nullptr, 0, nullptr, 1, nullptr};
+    FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, nullptr, Q, 0, nullptr, 0, nullptr, 1, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     const int npl = (N + 63) / 64;
     if (npl <= 1) return dispatch_currents_f<1>(a, d_currents, ldc, st);
@@ -1957,47 +2034,43 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     const int pt = 64 * (ppl ? ppl : 4);
     const int ntiles = (P + pt - 1) / pt;
 
-    int threads;
+    // Batch mode: the (tile, query) pairs, tile-major, are cut into equal runs, one per workgroup; a workgroup stages a
+    // tile once per run of its queries.  Four workgroups per CU's worth of work (the dispatcher evens out what the static
+    // cut does not, e.g. a CU that is busy with another stream's kernel), but at least ~6 queries per wavefront and run
+    // (the tile staging is paid per run), and a grid that is a whole number of rounds of the 256 CUs when it is small.
+    // An explicit n_groups > 0 asks for the (tile, query group) grid instead: one run per workgroup.
+    int threads, grid, Qv = Q;
+    long long W = 0;
     if (carry) {
         threads = 64;
+        grid = ntiles * n_groups;
     } else {
         threads = 1024;
-        if (n_groups <= 0) {
-            // about 16 queries per wavefront (the 100 KB tile is staged once per workgroup), but at least one
-            // workgroup per CU; measured on Q=4096: P=1000 -> 32 groups (256 workgroups), P=100000 -> 16
-            const int fill = ntiles < 256 ? 256 / ntiles : 1;   // rounded down: one workgroup over 256 costs a second round
-            const int load = (Q + 255) / 256;
-            const int most = (Q + 15) / 16;
-            n_groups = fill > load ? fill : load;
-            if (n_groups > most) n_groups = most;
-            if (n_groups < 1) n_groups = 1;
-            if ((long long)ntiles * n_groups > 256) {
-                // Several rounds of workgroups on the 256 CUs: the last round should be a full one.  Time ~ rounds / groups
-                // (a group's workgroup takes 1 / groups of the queries); 12 to 32 groups cost about the same otherwise
-                // (measured at 100 000 places: 16-24 flat, 12 +1 %, 32 +2 %).  12 501 places (an eighth of the database)
-                // go from 4.1 rounds of 16 groups to 6.96 rounds of 27.
-                double best = 0.0;
-                int best_g = n_groups;
-                const int g_lo = 12 < most ? 12 : most, g_hi = 32 < most ? 32 : most;
-                for (int g = g_lo; g <= g_hi; ++g) {
-                    const long long rounds = ((long long)ntiles * g + 255) / 256;
-                    const double pen = 1.0 + 0.0012 * (g > 24 ? g - 24 : 0) + 0.004 * (g < 16 ? 16 - g : 0);
-                    const double cost = (double)rounds / g * pen;
-                    if (g == g_lo || cost < best) { best = cost; best_g = g; }
-                }
-                n_groups = best_g;
-            }
+        if (n_groups > 0) {
+            if (n_groups > Q) n_groups = Q;
+            W = (Q + n_groups - 1) / n_groups;
+            Qv = (int)W * n_groups;
+            grid = ntiles * n_groups;
+        } else {
+            // tuning override: LENS_AMD_OUTPUT_ROUNDS=n cuts the work into n workgroups per CU (read once)
+            static const int rounds = [] { const char *e = getenv("LENS_AMD_OUTPUT_ROUNDS"); const int n = e ? atoi(e) : 0; return n >= 1 && n <= 64 ? n : 4; }();
+            const long long total = (long long)ntiles * Q;
+            const long long fine = (total + 95) / 96;                 // workgroups of 96 queries
+            long long nwg = fine <= NUM_CUS ? fine : fine < rounds * NUM_CUS ? (fine / NUM_CUS) * NUM_CUS : rounds * NUM_CUS;
+            if (nwg < 1) nwg = 1;
+            W = (total + nwg - 1) / nwg;
+            grid = (int)((total + W - 1) / W);
+            n_groups = 1;
         }
-        if (n_groups > Q) n_groups = Q;
     }
     OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? 1 : 0,
-              d_counts, ldo, ntiles};
+              d_counts, ldo, ntiles, Qv, W};
     switch (ppl) {
-    case 4: return launch_output<4, true>(a, threads, st);
-    case 3: return launch_output<3, true>(a, threads, st);
-    case 2: return launch_output<2, true>(a, threads, st);
-    case 1: return launch_output<1, true>(a, threads, st);
-    default: return launch_output<4, false>(a, threads, st);
+    case 4: return launch_output<4, true>(a, threads, grid, st);
+    case 3: return launch_output<3, true>(a, threads, grid, st);
+    case 2: return launch_output<2, true>(a, threads, grid, st);
+    case 1: return launch_output<1, true>(a, threads, grid, st);
+    default: return launch_output<4, false>(a, threads, grid, st);
     }
 }
 
@@ -2030,7 +2103,7 @@ int lens_forward_counts_static(const uint8_t *d_frames, int Q, int HW, const int
     if (P <= 0 || ldw2 < P || ldo < P || (carry && ldv < P)) return LENS_ERR_SIZE;
     if ((ldw2 & 255) || ((uintptr_t)d_w2t & 15)) return LENS_ERR_ALIGN;
     if (int e = lens_feature_events(d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, d_vfeat, split, carry,
-                                    events, (int)cap, nwords, lens_event_scale(F, P, carry, split), nullptr, stream))
+                                    events, (int)cap, nwords, lens_event_scale(F, P, carry, split), nullptr, nullptr, stream))
         return e;
     return lens_output_counts(events, (int)cap, nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, split, carry, d_counts, ldo,
                               stream);

@@ -111,7 +111,12 @@ class LensEngine:
         self.max_batch = int(max_batch)
         sel = centre_pixel_index(self.roi_dim, self.dims)
         self.sel = torch.from_numpy(sel).to(dev)
-        self.codes = build_threshold_codes(self.T, self.roi_dim, sel).to(dev)
+        codes = build_threshold_codes(self.T, self.roi_dim, sel)
+        self.codes = codes.to(dev)
+        # input spikes per (input neuron, pixel value): the feature kernel's load-balancing hint
+        steps = torch.empty((self.N, 256), dtype=torch.int16)
+        _lib.check(_lib.lib().lens_build_active_steps(_ptr(codes), self.T, self.N, _ptr(steps)), "lens_build_active_steps")
+        self.active_steps = steps.to(dev)
         # transposed, padded weight layouts the kernels read
         self.w1t = w1.t().contiguous().to(dev)                          # [N][F]
         self.ldw2 = (self.P + 255) // 256 * 256
@@ -205,7 +210,7 @@ class LensEngine:
         st = _lib.lib().lens_feature_events(
             _ptr(frames), Q, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
             _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), n_streams, int(carry),
-            _ptr(self.events), self.cap, _ptr(self.nwords), self.event_scale(carry), _ptr(spk), _stream())
+            _ptr(self.events), self.cap, _ptr(self.nwords), self.event_scale(carry), _ptr(spk), _ptr(self.active_steps), _stream())
         _lib.check(st, "lens_feature_events")
         return spk
 
@@ -294,7 +299,7 @@ class LensEngine:
                         st = L.lens_feature_events(
                             _ptr(fr), c1 - c0, self.HW, _ptr(self.sel), self.N, _ptr(self.codes), self.T,
                             _ptr(self.w1t), self.F, self.F, _ptr(self.v_feat), 1, 1,
-                            _ptr(ev), self.cap, _ptr(nw), scale, None, _stream())
+                            _ptr(ev), self.cap, _ptr(nw), scale, None, None, _stream())
                         _lib.check(st, "lens_feature_events")
                     done.record(side)
                 main.wait_event(done)

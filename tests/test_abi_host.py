@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 
 
 def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
-    assert L.lens_feature_events(None, 1, 1, None, 1, None, 1, None, 1, 1, None, 1, 0, None, 32, None, 1, None, None) == -1
+    assert L.lens_feature_events(None, 1, 1, None, 1, None, 1, None, 1, 1, None, 1, 0, None, 32, None, 1, None, None, None) == -1
     assert L.lens_output_counts(None, 16, None, 1, None, 1, 1, 256, None, 1, 1, 0, None, 1, None) == -1
     assert L.lens_seqmatch_topk(None, 1, 1, 1, 1, 1, 0, None, None, None) == -1
     assert L.lens_accumulate_events(None, None, 0, 8, None, None, None) == -1
@@ -56,6 +56,19 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     assert [L.lens_output_tile_places(200, p, 0, 0) for p in (64, 1000, 100000)] == [64, 128, 192]
     assert L.lens_output_tile_places(100, 100000, 0, 0) == 256 and L.lens_output_tile_places(700, 5, 0, 0) == 0
     assert L.lens_output_tile_places(200, 100000, 1, 1) == 64 and L.lens_event_scale(200, 100000, 1, 1) == 256
+
+
+def test_active_step_table_counts_input_spikes(L):
+    """lens_build_active_steps: table[n][p] = number of steps in which input n spikes at pixel value p, i.e. the row sums
+    of the raster (the feature kernel's load-balancing hint is the exact number of input spikes of a query)."""
+    rng = np.random.default_rng(3)
+    T, N = 37, 11
+    codes = rng.integers(1, 256, size=(T, N)).astype(np.uint8)
+    table = np.zeros((N, 256), dtype=np.uint16)
+    assert L.lens_build_active_steps(codes.ctypes.data_as(ctypes.c_void_p), T, N, table.ctypes.data_as(ctypes.c_void_p)) == 0
+    want = (np.arange(256)[None, None, :] >= codes[:, :, None]).sum(0)
+    assert np.array_equal(table, want)
+    assert L.lens_build_active_steps(None, T, N, table.ctypes.data_as(ctypes.c_void_p)) == -1
 
 
 def test_product_refuses_to_run_without_gpu():

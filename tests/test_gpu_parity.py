@@ -516,7 +516,7 @@ def test_two_pass_carried_feature_layer_writes_identical_streams(O):
                 else:
                     st = L.lens_feature_events(_ptr(fr), Q, eng.HW, _ptr(eng.sel), eng.N, _ptr(eng.codes), eng.T, _ptr(eng.w1t),
                                                eng.F, eng.F, _ptr(eng.v_feat), streams, 1, _ptr(eng.events), eng.cap,
-                                               _ptr(eng.nwords), eng.event_scale(True), None, _stream())
+                                               _ptr(eng.nwords), eng.event_scale(True), None, None, _stream())
                     assert st == 0
             torch.cuda.synchronize()
             nw = eng.nwords[:Q].cpu().numpy()
@@ -528,3 +528,37 @@ def test_two_pass_carried_feature_layer_writes_identical_streams(O):
             assert np.array_equal(ev0[q], ev1[q]), (w1.shape, T, q)
         assert np.array_equal(v0, v1)
         assert nw0.max() > 32 or w1.shape[0] == 64
+
+
+def test_dealing_queries_to_wavefronts_changes_no_stream(O):
+    """Batch mode with the load-balancing table: the 16 queries of a workgroup are dealt to its wavefronts by work.
+    Which wavefront integrates a query must not show: same stream lengths and words as without the table, for a batch
+    that ends in a partial workgroup, and the counts equal the oracle's."""
+    from lens_amd import _lib
+    from lens_amd.engine import _ptr, _stream
+    from lens_amd.synthetic import synthetic_frames
+    w1, w2p = pretrained_example()
+    eng = _engine(w1, w2p, 128, 10)
+    Q = 16 * 5 + 7
+    frames = synthetic_frames(Q, 128, seed=5)
+    frames[3] = 0
+    frames[20:24] = 200            # very heavy queries in one workgroup
+    fr = frames.cuda()
+    eng._workspace(Q)
+    got = []
+    for table in (None, eng.active_steps):
+        eng.events.fill_(-1); eng.nwords.fill_(-1)
+        st = _lib.lib().lens_feature_events(_ptr(fr), Q, eng.HW, _ptr(eng.sel), eng.N, _ptr(eng.codes), eng.T, _ptr(eng.w1t),
+                                            eng.F, eng.F, None, 0, 0, _ptr(eng.events), eng.cap, _ptr(eng.nwords),
+                                            eng.event_scale(False), None, _ptr(table), _stream())
+        assert st == 0
+        torch.cuda.synchronize()
+        nw = eng.nwords[:Q].cpu().numpy()
+        ev = eng.events[:Q].cpu().numpy()
+        got.append((nw, [ev[q, :nw[q]].copy() for q in range(Q)]))
+    assert np.array_equal(got[0][0], got[1][0])
+    for q in range(Q):
+        assert np.array_equal(got[0][1][q], got[1][1][q]), q
+    out = eng.output_counts(Q, carry=False).cpu().numpy()
+    ref = O.forward(frames.numpy(), 10, O.rand_U(250, 128 * 128), np.asarray(w1, np.float32), np.asarray(w2p, np.float32), carry=False)
+    assert np.array_equal(out, ref)

@@ -711,8 +711,7 @@ struct OutArgs {
     float *vout; int ldv; int n_groups; int carry;
     float *counts; int ldo;
     int ntiles;
-    int Qv;          // queries per tile in the list of (tile, query) pairs (Q, or Q padded to whole groups of an explicit split)
-    long long W;     // batch mode: pairs per workgroup
+    int n_whole;     // batch mode: the first n_whole workgroups take a whole tile each (all queries)
 };
 
 template <int PPL> struct VecT;
@@ -905,47 +904,35 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
-    // Work = all (tile, query) pairs, tile-major.  Carried state: workgroup = (tile, stream), ONE wavefront, which walks
-    // the stream's queries in order.  Batch mode: workgroup b owns the pairs [b * W, (b + 1) * W) -- a run of queries of
-    // one tile, then of the next ones -- so a tile is staged once per run, not once per (tile, query group), and the
-    // 16 wavefronts pull the queries of a run first come, first served (stream lengths vary by +-20 % (std) between
-    // queries; with a fixed assignment the slowest wavefront sets the pace): they idle only at the end of a run, a
-    // few times per launch.  The kernel owns no static LDS: the tile starts at LDS address 0 (the assembly loop of the
-    // 192-place tile relies on it, launch_output checks it) and the bookkeeping sits behind the tile in the same block.
+    // Carried state: workgroup = (tile, stream), ONE wavefront, which walks the stream's queries in order.
+    // Batch mode: the first n_whole workgroups (a multiple of the CU count) take one WHOLE tile each, all Q queries: the
+    // tile is staged once, the 16 wavefronts pull queries first come, first served (stream lengths vary by +-20 % (std)
+    // between queries; with a fixed assignment the slowest wavefront sets the pace) and idle only at the very end, and
+    // all workgroups of a round walk the queries at the same pace, so a stream is fetched from memory once per XCD and
+    // round and found in that L2 by the other workgroups.  The remaining tiles (fewer than the CUs) are split into
+    // n_groups query groups each so that they fill the CUs once more: workgroup = (tile, group), group-major.
+    // The kernel owns no static LDS: the tile starts at LDS address 0 (the assembly loop of the 192-place tile relies on
+    // it, launch_output checks it) and the bookkeeping sits behind the tile in the same dynamic block.
     unsigned char *book = smem + (W_LDS ? (size_t)a.F * PT * 4 : 0);
     uint32_t *s_len = reinterpret_cast<uint32_t *>(book);                              // [OUT_ORDER_MAX]
-    uint16_t *s_order = reinterpret_cast<uint16_t *>(book + OUT_ORDER_MAX * 4);          // longest stream first (when the run is small enough to rank)
+    uint16_t *s_order = reinterpret_cast<uint16_t *>(book + OUT_ORDER_MAX * 4);          // longest stream first (when the group is small enough to rank)
     int &s_next = *reinterpret_cast<int *>(book + (a.carry ? 0 : OUT_ORDER_MAX * 6));   // carried state: the book is this word only
 
-    long long lo, hi;                        // this workgroup's pairs, in units of Qv (virtual queries per tile) per tile
-    int grp = 0;
-    if (a.carry) {
-        const int tile = blockIdx.x % a.ntiles;
-        grp = blockIdx.x / a.ntiles;
-        lo = (long long)tile * a.Qv + (int)(((long long)grp * a.Q) / a.n_groups);
-        hi = (long long)tile * a.Qv + (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
-        if (wave != 0) return;               // a carried stream is sequential: one wavefront per tile
+    int tile, grp = 0, qs = 0, qe = a.Q;
+    if ((int)blockIdx.x < a.n_whole) {
+        tile = blockIdx.x;
     } else {
-        lo = (long long)blockIdx.x * a.W;
-        hi = lo + a.W;
-        const long long all = (long long)a.ntiles * a.Qv;
-        if (hi > all) hi = all;
+        const int r = blockIdx.x - a.n_whole, rem = a.ntiles - a.n_whole;
+        tile = a.n_whole + r % rem;
+        grp = r / rem;
+        qs = (int)(((long long)grp * a.Q) / a.n_groups);
+        qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
     }
+    if (a.carry && wave != 0) return;        // a carried stream is sequential: one wavefront per tile
     const uint32_t lane_off = (uint32_t)lane * (PPL == 3 ? 8 : PPL * 4);
-    bool first_run = true;
-    while (lo < hi) {
-        const int tile = (int)(lo / a.Qv);
-        const int qs = (int)(lo - (long long)tile * a.Qv);
-        long long run = (long long)a.Qv - qs;
-        if (run > hi - lo) run = hi - lo;
-        lo += run;
-        int qe = qs + (int)run;
-        if (qe > a.Q) qe = a.Q;              // (virtual queries beyond Q pad the last group of an explicit split)
+    {
         const int nq = qe - qs;
-        if (nq <= 0) continue;
         const int p0 = tile * PT;
-        if (!first_run) __syncthreads();     // every wavefront has finished with the previous tile
-        first_run = false;
         if (threadIdx.x == 0) s_next = 0;
         if constexpr (W_LDS) {
             float4 *dst = reinterpret_cast<float4 *>(smem);
@@ -964,9 +951,8 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
                 }
             }
         }
-        // Longest first pays when the whole grid is one or two rounds of short runs (the tail of the slowest workgroup
-        // is the kernel's tail); in a long run the first-come-first-served hand-out evens things out by itself and the
-        // O(nq^2) ranking would be a net loss.
+        // Longest first pays when the whole grid is one or two rounds of workgroups (the tail of the slowest one is the
+        // kernel's tail); with many rounds the dispatcher evens things out and the O(nq^2) ranking is a net loss.
         const bool ranked = !a.carry && nq <= OUT_ORDER_MAX && gridDim.x <= 512;
         if (ranked) {
             for (int t = threadIdx.x; t < nq; t += blockDim.x) s_len[t] = a.nwords[qs + t];
@@ -2034,37 +2020,53 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     const int pt = 64 * (ppl ? ppl : 4);
     const int ntiles = (P + pt - 1) / pt;
 
-    // Batch mode: the (tile, query) pairs, tile-major, are cut into equal runs, one per workgroup; a workgroup stages a
-    // tile once per run of its queries.  Four workgroups per CU's worth of work (the dispatcher evens out what the static
-    // cut does not, e.g. a CU that is busy with another stream's kernel), but at least ~6 queries per wavefront and run
-    // (the tile staging is paid per run), and a grid that is a whole number of rounds of the 256 CUs when it is small.
-    // An explicit n_groups > 0 asks for the (tile, query group) grid instead: one run per workgroup.
-    int threads, grid, Qv = Q;
-    long long W = 0;
+    // Batch mode: whole tiles for as many full rounds of the CUs as there are (a workgroup = one tile x all queries), the
+    // remaining tiles split into query groups (see the kernel).  An explicit n_groups > 0 splits every tile that way.
+    int threads, grid, n_whole = 0;
     if (carry) {
         threads = 64;
         grid = ntiles * n_groups;
     } else {
         threads = 1024;
-        if (n_groups > 0) {
-            if (n_groups > Q) n_groups = Q;
-            W = (Q + n_groups - 1) / n_groups;
-            Qv = (int)W * n_groups;
-            grid = ntiles * n_groups;
-        } else {
-            // tuning override: LENS_AMD_OUTPUT_ROUNDS=n cuts the work into n workgroups per CU (read once)
-            static const int rounds = [] { const char *e = getenv("LENS_AMD_OUTPUT_ROUNDS"); const int n = e ? atoi(e) : 0; return n >= 1 && n <= 64 ? n : 4; }();
-            const long long total = (long long)ntiles * Q;
-            const long long fine = (total + 95) / 96;                 // workgroups of 96 queries
-            long long nwg = fine <= NUM_CUS ? fine : fine < rounds * NUM_CUS ? (fine / NUM_CUS) * NUM_CUS : rounds * NUM_CUS;
-            if (nwg < 1) nwg = 1;
-            W = (total + nwg - 1) / nwg;
-            grid = (int)((total + W - 1) / W);
-            n_groups = 1;
+        if (n_groups <= 0) {
+            // tuning override: LENS_AMD_OUTPUT_WHOLE=0 switches the whole-tile rounds off (read once)
+            static const int whole = [] { const char *e = getenv("LENS_AMD_OUTPUT_WHOLE"); return e ? atoi(e) : 1; }();
+            if (whole && Q >= 16 * 64) n_whole = (ntiles / NUM_CUS) * NUM_CUS;       // (a tile's queries must keep 16 wavefronts busy)
+            const int rem = ntiles - n_whole;
+            if (rem > 0) {
+                // about 16 queries per wavefront (the tile is staged once per workgroup), but at least one workgroup per
+                // CU; measured on Q=4096: P=1000 -> 32 groups (256 workgroups)
+                const int fill = rem < NUM_CUS ? NUM_CUS / rem : 1;   // rounded down: one workgroup over 256 costs a second round
+                const int load = (Q + 255) / 256;
+                const int most = (Q + 15) / 16;
+                n_groups = fill > load ? fill : load;
+                if (n_groups > most) n_groups = most;
+                if (n_groups < 1) n_groups = 1;
+                if ((long long)rem * n_groups > NUM_CUS) {
+                    // Several rounds of workgroups on the 256 CUs: the last round should be a full one.  Time ~ rounds / groups
+                    // (a group's workgroup takes 1 / groups of the queries); 12 to 32 groups cost about the same otherwise
+                    // (measured at 100 000 places: 16-24 flat, 12 +1 %, 32 +2 %).  12 501 places (an eighth of the database)
+                    // go from 4.1 rounds of 16 groups to 6.96 rounds of 27.
+                    double best = 0.0;
+                    int best_g = n_groups;
+                    const int g_lo = 12 < most ? 12 : most, g_hi = 32 < most ? 32 : most;
+                    for (int g = g_lo; g <= g_hi; ++g) {
+                        const long long rounds = ((long long)rem * g + NUM_CUS - 1) / NUM_CUS;
+                        const double pen = 1.0 + 0.0012 * (g > 24 ? g - 24 : 0) + 0.004 * (g < 16 ? 16 - g : 0);
+                        const double cost = (double)rounds / g * pen;
+                        if (g == g_lo || cost < best) { best = cost; best_g = g; }
+                    }
+                    n_groups = best_g;
+                }
+            } else {
+                n_groups = 1;
+            }
         }
+        if (n_groups > Q) n_groups = Q;
+        grid = n_whole + (ntiles - n_whole) * n_groups;
     }
     OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? 1 : 0,
-              d_counts, ldo, ntiles, Qv, W};
+              d_counts, ldo, ntiles, n_whole};
     switch (ppl) {
     case 4: return launch_output<4, true>(a, threads, grid, st);
     case 3: return launch_output<3, true>(a, threads, grid, st);

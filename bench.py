@@ -180,7 +180,7 @@ def recall_identity(idx, K_list=(1, 5, 25)):
 # Step time of ONE GPU at a per-rank database size (places incl. the halo row, 4096 queries, synthetic density), measured
 # with `bench.py --places <n>`: what each rank of a DB-sharded run is expected to take, the all-gather and merge being
 # overlapped with the next step's kernels.  A projection to compare the first multi-GPU measurement with, not a result.
-SINGLE_GPU_STEP_MS = {12501: 2.13, 25001: 3.98, 50001: 7.61, 100000: 14.55}
+SINGLE_GPU_STEP_MS = {12501: 2.10, 25001: 3.94, 50001: 7.22, 100000: 13.95}
 
 
 def expected_sharded_ms(places_per_rank, queries):
@@ -440,6 +440,10 @@ def main():
                 pm = json.load(fh).get(f"P{P_local}_Q{Q}", {}).get(names[dom])
             if pm:
                 roof["traffic"] = pm.get("hbm_bytes_per_launch")
+                if dom == 1 and pm.get("SQ_INSTS_VALU"):
+                    # the instruction-issue view: vector instructions per launch (committed PMC pass of this workload) over
+                    # THIS run's launch time and the SIMDs' issue rate
+                    roof["valu_issue_frac"] = pm["SQ_INSTS_VALU"] / (N_SIMD * avg_ms[dom] * 1e6 * VALU_ISSUE_PER_NS)
                 roof["offline_profile"] = dict(pm, note="rocprofv3 --pmc passes of this workload committed under "
                                                "profiles/ (not measured in this run); valu_issue_frac = SQ_INSTS_VALU "
                                                "/ (1024 SIMDs x launch time x 1.2 VALU/ns)")

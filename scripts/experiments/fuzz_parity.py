@@ -49,6 +49,21 @@ for case in range(n_cases):
         if not np.array_equal(out.cpu().numpy(), ref, equal_nan=True):
             print("MISMATCH", dict(case=case, dims=dims, k=k, F=F, P=P, T=T, Q=Q, w1s=w1s, w2s=w2s, dens=dens, carry=carry))
             sys.exit(1)
+    # several carried streams: contiguous runs of the batch, each with its own state (and a second call on that state)
+    ns = int(rng.integers(2, 6))
+    if Q >= ns:
+        eng.reset_state(ns)
+        bounds = [s * Q // ns for s in range(ns + 1)]
+        states = [O.State(N, F, P) for _ in range(ns)]
+        for rep in range(2):
+            outs = eng.forward_counts(torch.from_numpy(frames).cuda(), carry=True).cpu().numpy()
+            for si in range(ns):
+                a, b = bounds[si], bounds[si + 1]
+                refs = O.forward(frames[a:b], dims, U, w1, w2, carry=True, state=states[si])
+                if not np.array_equal(outs[a:b], refs, equal_nan=True):
+                    print("MISMATCH (streams)", dict(case=case, dims=dims, k=k, F=F, P=P, T=T, Q=Q, ns=ns, stream=si, rep=rep, w1s=w1s, w2s=w2s, dens=dens))
+                    sys.exit(1)
+        eng.reset_state()
     L = int(rng.choice([1, 2, 3]))
     if Q >= L and P >= L and np.isfinite(ref).all():
         S = O.seqmatch(ref, L)
@@ -64,6 +79,6 @@ for case in range(n_cases):
             print(" gpu idx", g[r].tolist()); print(" ref idx", oi[r].tolist()); print(" gpu val", gvv[r].tolist()); print(" ref val", ov[r].tolist())
             print(" S col", S[:, r].tolist()[:80])
             sys.exit(1)
-    if case % 10 == 9:
+    if case % 10 == 9 or BIG:        # (a big case takes the oracle a minute or more: keep the log moving)
         print(f"  {case + 1} cases, {time.time() - t0:.0f} s", flush=True)
 print(f"{n_cases} cases ok in {time.time() - t0:.1f} s")

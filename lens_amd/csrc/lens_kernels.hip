@@ -711,7 +711,9 @@ struct OutArgs {
     float *vout; int ldv; int n_groups; int carry;
     float *counts; int ldo;
     int ntiles;
-    int n_whole;     // batch mode: the first n_whole workgroups take a whole tile each (all queries)
+    int n_whole;     // batch mode: workgroups of the main part (whole rounds of the CUs), 0 = none
+    int n_main;      // ... tiles per round of the main part
+    int g_main;      // ... query groups per tile there (1: a workgroup takes a whole tile)
 };
 
 template <int PPL> struct VecT;
@@ -905,12 +907,14 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
     // Carried state: workgroup = (tile, stream), ONE wavefront, which walks the stream's queries in order.
-    // Batch mode: the first n_whole workgroups (a multiple of the CU count) take one WHOLE tile each, all Q queries: the
-    // tile is staged once, the 16 wavefronts pull queries first come, first served (stream lengths vary by +-20 % (std)
-    // between queries; with a fixed assignment the slowest wavefront sets the pace) and idle only at the very end, and
-    // all workgroups of a round walk the queries at the same pace, so a stream is fetched from memory once per XCD and
-    // round and found in that L2 by the other workgroups.  The remaining tiles (fewer than the CUs) are split into
-    // n_groups query groups each so that they fill the CUs once more: workgroup = (tile, group), group-major.
+    // Batch mode: the first n_whole workgroups form whole rounds of the CUs, one workgroup per CU: each takes one tile
+    // and all Q queries (or, for a database of fewer tiles than CUs, the 1/2, 1/4 ... of them that makes the round
+    // full): the tile is staged once, the 16 wavefronts pull queries first come, first served (stream lengths vary
+    // by +-20 % (std) between queries; with a fixed assignment the slowest wavefront sets the pace) and idle only at
+    // the very end, and all workgroups of a round walk their queries at the same pace, so a stream is fetched from
+    // memory once per XCD and round and found in that L2 by the other workgroups.  The remaining tiles (fewer than a
+    // round) are split into n_groups query groups each so that they fill the CUs once more: workgroup = (tile, group),
+    // group-major.
     // The kernel owns no static LDS: the tile starts at LDS address 0 (the assembly loop of the 192-place tile relies on
     // it, launch_output checks it) and the bookkeeping sits behind the tile in the same dynamic block.
     unsigned char *book = smem + (W_LDS ? (size_t)a.F * PT * 4 : 0);
@@ -920,10 +924,17 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 
     int tile, grp = 0, qs = 0, qe = a.Q;
     if ((int)blockIdx.x < a.n_whole) {
-        tile = blockIdx.x;
+        // a round of the main part = n_main tiles x g_main query groups = one workgroup per CU, group-major (neighbouring
+        // workgroups, which land on different XCDs, share a group's queries); g_main = 1 where the tiles alone fill the CUs
+        const int per_round = a.n_main * a.g_main, j = blockIdx.x % per_round;
+        tile = (blockIdx.x / per_round) * a.n_main + j % a.n_main;
+        grp = j / a.n_main;
+        qs = (int)(((long long)grp * a.Q) / a.g_main);
+        qe = (int)(((long long)(grp + 1) * a.Q) / a.g_main);
     } else {
-        const int r = blockIdx.x - a.n_whole, rem = a.ntiles - a.n_whole;
-        tile = a.n_whole + r % rem;
+        const int first = (a.n_whole / (a.n_main * a.g_main)) * a.n_main;     // tiles of the main part
+        const int r = blockIdx.x - a.n_whole, rem = a.ntiles - first;
+        tile = first + r % rem;
         grp = r / rem;
         qs = (int)(((long long)grp * a.Q) / a.n_groups);
         qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
@@ -2022,7 +2033,7 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
 
     // Batch mode: whole tiles for as many full rounds of the CUs as there are (a workgroup = one tile x all queries), the
     // remaining tiles split into query groups (see the kernel).  An explicit n_groups > 0 splits every tile that way.
-    int threads, grid, n_whole = 0;
+    int threads, grid, n_whole = 0, n_main = NUM_CUS, g_main = 1;
     if (carry) {
         threads = 64;
         grid = ntiles * n_groups;
@@ -2031,8 +2042,16 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
         if (n_groups <= 0) {
             // tuning override: LENS_AMD_OUTPUT_WHOLE=0 switches the whole-tile rounds off (read once)
             static const int whole = [] { const char *e = getenv("LENS_AMD_OUTPUT_WHOLE"); return e ? atoi(e) : 1; }();
-            if (whole && Q >= 16 * 64) n_whole = (ntiles / NUM_CUS) * NUM_CUS;       // (a tile's queries must keep 16 wavefronts busy)
-            const int rem = ntiles - n_whole;
+            // main part: query groups per tile = the smallest power of two that makes the tiles fill the CUs, as long as a
+            // workgroup keeps >= 16 queries per wavefront
+            while (ntiles * g_main < NUM_CUS) g_main *= 2;
+            if (whole && Q / g_main >= 16 * 16) {
+                n_main = NUM_CUS / g_main;
+                n_whole = (ntiles / n_main) * NUM_CUS;
+            } else {
+                g_main = 1;
+            }
+            const int rem = ntiles - (n_whole / NUM_CUS) * n_main;
             if (rem > 0) {
                 // about 16 queries per wavefront (the tile is staged once per workgroup), but at least one workgroup per
                 // CU; measured on Q=4096: P=1000 -> 32 groups (256 workgroups)
@@ -2063,10 +2082,10 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
             }
         }
         if (n_groups > Q) n_groups = Q;
-        grid = n_whole + (ntiles - n_whole) * n_groups;
+        grid = n_whole + (ntiles - (n_whole / NUM_CUS) * n_main) * n_groups;
     }
     OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? 1 : 0,
-              d_counts, ldo, ntiles, n_whole};
+              d_counts, ldo, ntiles, n_whole, n_main, g_main};
     switch (ppl) {
     case 4: return launch_output<4, true>(a, threads, grid, st);
     case 3: return launch_output<3, true>(a, threads, grid, st);

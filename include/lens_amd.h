@@ -172,8 +172,8 @@ size_t lens_feature_fire_scratch_bytes(int T, int F, int n_streams);
  * and writes the spike streams of lens_feature_events (same layout, same bits).
  * d_vfeat [n_streams][F] carried state, read and written; queries are split into n_streams contiguous runs as in
  * lens_feature_events.  d_scratch: lens_feature_fire_scratch_bytes(T, F, n_streams) bytes, 4-byte aligned, contents
- * irrelevant.  d_currents: as written by lens_feature_currents, with its slack rows.  F <= 1024; T * ceil(F/64) * 24 bytes
- * of tables must fit LDS (else LENS_ERR_UNSUPPORTED: use
+ * irrelevant.  d_currents: as written by lens_feature_currents, with its slack rows.  F <= 768; about T * (ceil(F/64) * 24 + 32)
+ * bytes of tables must fit LDS (else LENS_ERR_UNSUPPORTED: use
  * lens_feature_events).
  */
 int lens_feature_fire(const float *d_currents, int ldc, int Q, int T, int F,

@@ -443,10 +443,10 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
 //   pass 2  k_feature_fire      (one workgroup per carried stream, sequential in the query index): wavefront w owns
 //           features [64w, 64w+64) -- they are independent of each other given I -- and walks the T steps without
 //           any synchronisation: one prefetched load, the IAF update on ONE register, and on a step in which its
-//           lanes fire the 64-bit spike mask into its row of an LDS table.  After the last step one barrier, then the
-//           workgroup expands the masks into the spike stream (thread = time step): per-step totals, a prefix sum
-//           for the positions, the LAST / EMPTY_NEXT / CHUNK_MIXED flags and explicit empty steps exactly as the
-//           one-pass writer of k_feature_events produces them (the streams are bit-identical).
+//           lanes fire the 64-bit spike mask into its row of an LDS table.  While the walkers go on with the next query,
+//           four helper wavefronts expand the masks into the spike stream: per-step totals, a prefix sum for the
+//           positions, the LAST / EMPTY_NEXT / CHUNK_MIXED flags and explicit empty steps exactly as the one-pass
+//           writer of k_feature_events produces them (the streams are bit-identical); one barrier per query.
 //           The currents buffer carries FIRE_DEPTH rows of slack behind its last query: the walk prefetches that far.
 // ------------------------------------------------------------------------------------------
 template <int NPL, int FPL, bool USE_LDS>
@@ -516,8 +516,8 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_currents
 }
 
 constexpr int FIRE_DEPTH = 32;         // steps whose currents are in flight per wavefront of k_feature_fire (fire_loop.inc)
-constexpr int FIRE_MAX_WAVES = 16;     // features <= 1024
-constexpr int FIRE_THREADS = 1024;     // workgroup of k_feature_fire: the walking wavefronts plus helpers for the merge
+constexpr int FIRE_HELPERS = 4;        // wavefronts of k_feature_fire that expand the masks of the previous query
+constexpr int FIRE_MAX_WAVES = 16 - FIRE_HELPERS;   // walking wavefronts: features <= 768
 static_assert(FIRE_DEPTH == LENS_FIRE_SLACK_ROWS, "the slack the header asks for is the walk's prefetch depth");
 
 struct FireArgs {
@@ -540,43 +540,154 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
     return x;
 }
 
+// Expansion of one query's spike masks into its stream by ONE helper wavefront (lane = time step, then lane = (step,
+// walking wavefront) item); FIRE_HELPERS of them share the items and compute the positions each for itself (own copy of
+// the per-step arrays: nothing to synchronise between them).
+struct FireTables {
+    const uint64_t *mask;     // [NW][T] lanes that fired
+    const uint32_t *flag;     // [NW][T] 1: some count of the (wavefront, step) is above 1 -> counts[k][t][64]
+    const float *counts;
+    uint32_t *pos;            // [T + 1] this helper's own: stream position of each step
+    uint32_t *tot;            // [T]     ... events of each step
+    uint32_t *mixed;          // bitmap over chunks
+};
+
+__device__ __forceinline__ void fire_expand(const FireArgs &a, const FireTables &tb, int NW, int q, int h, int lane)
+{
+    const int T = a.T;
+    const int mixed_words = (a.cap / EV_WORDS + 31) / 32;
+    auto count_bits = [&](int k, int t, int l) {   // count word of lane l's event of (wavefront k, step t)
+        if (!tb.flag[(size_t)k * T + t]) return 0x3f800000u;
+        return __hip_atomic_load(reinterpret_cast<const uint32_t *>(tb.counts) + ((size_t)k * T + t) * 64 + l,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto step_total = [&](int t) {
+        uint32_t n = 0;
+        for (int k = 0; k < NW; ++k) n += (uint32_t)__builtin_popcountll(tb.mask[(size_t)k * T + t]);
+        return n;
+    };
+    auto step_big = [&](int t) {       // count of the step's last event >= 2^23 (the step has events)
+        for (int k = NW - 1; k >= 0; --k) {
+            const uint64_t m = tb.mask[(size_t)k * T + t];
+            if (m) return count_bits(k, t, 63 - __builtin_clzll(m)) >= 0x4b000000u;
+        }
+        return false;
+    };
+    for (int i = lane; i < mixed_words; i += 64) tb.mixed[i] = 0u;
+    // sizes of the steps (their events, or 1 for an explicit empty step) and their prefix sum, 64 steps per round
+    uint32_t carry = 0;
+    bool any = false;                  // some step needs the chunk-marking pass
+    for (int b = 0; b < T; b += 64) {
+        const int t = b + lane;
+        uint32_t size = 0;
+        if (t < T) {
+            const uint32_t tot = step_total(t);
+            // an empty step that must be written as the event {0, -0.0f}: step 0, or after a count >= 2^23
+            const bool expl = tot == 0 && (t == 0 || (step_total(t - 1) != 0 && step_big(t - 1)));
+            tb.tot[t] = tot;
+            size = tot + (expl ? 1u : 0u);
+            if (tot) for (int k = 0; k < NW; ++k) any |= tb.flag[(size_t)k * T + t] != 0;
+            any |= expl;
+        }
+        const uint32_t inc = wave_inclusive_sum(size);
+        if (t < T) tb.pos[t + 1] = carry + inc;          // position after step t
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (lane == 0) tb.pos[0] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the arrays are read by other lanes of this wavefront below
+    __builtin_amdgcn_wave_barrier();
+    if (__ballot(any) != 0) {          // chunks that hold a count other than 1 (explicit empty steps, counts above 1)
+        for (int t = lane; t < T; t += 64) {
+            uint32_t p = tb.pos[t];
+            if (tb.pos[t + 1] - p == 0) continue;
+            if (tb.tot[t] == 0) { atomicOr(&tb.mixed[(p >> 4) >> 5], 1u << ((p >> 4) & 31)); continue; }
+            for (int k = 0; k < NW; ++k) {
+                const uint64_t m = tb.mask[(size_t)k * T + t];
+                if (tb.flag[(size_t)k * T + t]) {
+                    uint32_t pe = p;
+                    for (uint64_t mm = m; mm; mm &= mm - 1, ++pe)
+                        if (count_bits(k, t, __builtin_ctzll(mm)) > 0x3f800000u) atomicOr(&tb.mixed[(pe >> 4) >> 5], 1u << ((pe >> 4) & 31));
+                }
+                p += (uint32_t)__builtin_popcountll(m);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t *ev = a.events + (size_t)q * a.cap;
+    // one item per (step, walking wavefront): that wavefront's events of the step, behind those of the lower ones;
+    // the helpers take the items in turns of 64
+    for (int i = h * 64 + lane; i < T * NW; i += FIRE_HELPERS * 64) {
+        const int t = i / NW, k = i - t * NW;
+        uint32_t p = tb.pos[t];
+        if (tb.pos[t + 1] - p == 0) continue;
+        // the step(s) that follow carry no spikes and are not written: flag on this step's LAST event
+        const bool empty_next = (t + 1 < T) && (tb.pos[t + 2] - tb.pos[t + 1] == 0);
+        auto put = [&](uint32_t pos, uint32_t w0, uint32_t w1) {
+            if ((pos & (EV_CHUNK - 1)) == 0 && ((tb.mixed[(pos >> 4) >> 5] >> ((pos >> 4) & 31)) & 1u)) w0 |= EV_CHUNK_MIXED;
+            reinterpret_cast<uint2 *>(ev)[pos] = make_uint2(w0, w1);
+        };
+        const uint32_t tot = tb.tot[t];
+        if (tot == 0) {                // explicit empty step
+            if (k == 0) put(p, 0u, EV_LAST | (empty_next ? EV_EMPTY_NEXT : 0u));
+            continue;
+        }
+        uint64_t m = tb.mask[(size_t)k * T + t];
+        if (!m) continue;
+        const uint32_t last = p + tot - 1;
+        for (int j = 0; j < k; ++j) p += (uint32_t)__builtin_popcountll(tb.mask[(size_t)j * T + t]);
+        const bool counted = tb.flag[(size_t)k * T + t] != 0;      // counts above 1 in this (wavefront, step): rare
+        for (; m; m &= m - 1) {
+            const int l = __builtin_ctzll(m);
+            uint32_t w1 = counted ? count_bits(k, t, l) : 0x3f800000u;
+            if (p == last) w1 |= EV_LAST | ((empty_next && (w1 & 0x7fffffffu) < 0x4b000000u) ? EV_EMPTY_NEXT : 0u);
+            put(p, (uint32_t)(k * 64 + l) * (uint32_t)a.ev_scale, w1);
+            ++p;
+        }
+    }
+    if (h == 0) {
+        const uint32_t count = tb.pos[T];
+        const uint32_t pad = ((uint32_t)EV_CHUNK - (count & (EV_CHUNK - 1))) & (EV_CHUNK - 1);
+        if ((uint32_t)lane < pad) reinterpret_cast<uint2 *>(ev)[count + lane] = make_uint2(0u, 0x3f800000u);
+        if (lane == 0) a.nwords[q] = 2u * (count + pad);
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_feature_fire(FireArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // NW wavefronts walk (one per 64 features); the workgroup is launched with more (FIRE_THREADS) so that the merge,
-    // which is all latency, has several wavefronts per SIMD to hide it: the extra ones wait at the walk's barrier.
+    // Workgroup = NW walking wavefronts (one per 64 features) + FIRE_HELPERS helper wavefronts.  Software pipeline over
+    // the stream's queries, ONE barrier per iteration: in iteration i the walkers walk query i while the helpers expand
+    // the masks of query i - 1 into its stream, so the expansion costs the walk nothing as long as it is the shorter.
     const int NW = (a.F + 63) >> 6;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int T = a.T;
     // per (wavefront, step): the 64-bit mask of the lanes that fired (0: no event) and a flag word (1: some count of the
     // step is above 1; the 64 counts are then in the wavefront's scratch row of the step) -- two sets, used by
-    // alternate queries, so that a wavefront can start the next query while others still expand this one's masks;
-    // per step: its size in the stream (its events, or 1 for an explicit empty step) -> its position
+    // alternate queries; per helper: positions and sizes of the steps, bitmap of the chunks with a count other than 1
     const size_t set_bytes = ((size_t)NW * T * 12 + 7) & ~(size_t)7;
-    uint32_t *s_pos = reinterpret_cast<uint32_t *>(smem + 2 * set_bytes);      // [T + 1]
-    uint32_t *s_tot = s_pos + (T + 1);                                         // [T] events of the step
-    uint32_t *s_mixed = s_tot + T;                                             // bitmap over chunks: [(cap / 32 + 31) / 32]
     const int mixed_words = (a.cap / EV_WORDS + 31) / 32;
-    uint32_t *s_any = s_mixed + mixed_words;                                   // some step needs the chunk-marking pass
+    const size_t helper_words = (size_t)(2 * T + 1) + mixed_words;
     const int s = blockIdx.x;
     const int qs = (int)(((long long)s * a.Q) / a.n_streams);
     const int qe = (int)(((long long)(s + 1) * a.Q) / a.n_streams);
     const int f = w * 64 + lane;
-    float v = (f < a.F) ? a.vfeat[(size_t)s * a.F + f] : 0.0f;
+    const bool walker = w < NW;
+    float v = (walker && f < a.F) ? a.vfeat[(size_t)s * a.F + f] : 0.0f;
     const float *counts_sets = a.scratch + (size_t)s * 2 * NW * ((size_t)T * 64);   // [2][NW][T][64] spike counts of flagged steps
     using lds_ptr = __attribute__((address_space(3))) unsigned char *;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
-    for (int q = qs; q < qe; ++q) {
-        const size_t set = (size_t)((q - qs) & 1) * set_bytes;
-        uint64_t *s_mask = reinterpret_cast<uint64_t *>(smem + set);                        // [NW][T]
-        uint32_t *s_flag = reinterpret_cast<uint32_t *>(smem + set + (size_t)NW * T * 8);   // [NW][T]
-        const float *counts_all = counts_sets + (size_t)((q - qs) & 1) * NW * ((size_t)T * 64);     // (alternating like the tables)
-        // ---------------- the T steps, every wavefront on its own (it touches only its own rows of the tables)
-        if (w < NW) {
+    for (int it = 0; it <= qe - qs; ++it) {
+        if (walker && it < qe - qs) {
+            // ---------------- the T steps of query qs + it, every walker on its own (it touches only its rows of the tables)
+            const int q = qs + it;
+            const size_t set = (size_t)(it & 1) * set_bytes;
+            uint64_t *s_mask = reinterpret_cast<uint64_t *>(smem + set);                        // [NW][T]
+            uint32_t *s_flag = reinterpret_cast<uint32_t *>(smem + set + (size_t)NW * T * 8);   // [NW][T]
             for (int t = lane; t < T; t += 64) { s_mask[(size_t)w * T + t] = 0ull; s_flag[(size_t)w * T + t] = 0u; }
             const float *row0 = a.cur + (size_t)q * T * a.ldc;              // wave-uniform
-            const float *sc = counts_all + (size_t)w * ((size_t)T * 64);
+            const float *sc = counts_sets + ((size_t)(it & 1) * NW + w) * ((size_t)T * 64);
             uint64_t hot = ~0ull;         // lanes whose membrane is exactly 1.0; all ones: step 0 always runs
             uint32_t tab = lds0 + (uint32_t)(set + ((size_t)w * T) * 8);
             uint32_t flg = lds0 + (uint32_t)(set + (size_t)NW * T * 8 + ((size_t)w * T) * 4);
@@ -592,110 +703,23 @@ __global__ void __launch_bounds__(1024) k_feature_fire(FireArgs a)
                   "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
                   "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
                   "v96", "v97", "v98", "v99");
+        } else if (!walker && it >= 1) {
+            // ---------------- the stream of query qs + it - 1 from the other set of tables
+            const int h = w - NW;
+            const size_t set = (size_t)((it - 1) & 1) * set_bytes;
+            uint32_t *mine = reinterpret_cast<uint32_t *>(smem + 2 * set_bytes) + (size_t)h * helper_words;
+            FireTables tb{reinterpret_cast<const uint64_t *>(smem + set),
+                          reinterpret_cast<const uint32_t *>(smem + set + (size_t)NW * T * 8),
+                          counts_sets + (size_t)((it - 1) & 1) * NW * ((size_t)T * 64),
+                          mine, mine + (T + 1), mine + (2 * T + 1)};
+            fire_expand(a, tb, NW, qs + it - 1, h, lane);
         }
-        // The (rare) count rows are read by the other wavefronts of this workgroup only: the walk ends with
-        // s_waitcnt vmcnt(0) (the stores have reached L2) and the readers load them past their L1 (agent-scope atomic
-        // loads), so the barrier's workgroup-scope fence is enough.  No wavefront is still in the previous query's
-        // merge once all have arrived here, so the per-step arrays below can be rewritten.
+        // The tables (LDS) and the rare count rows (global: the walk ends with s_waitcnt vmcnt(0), the helpers read them
+        // past their L1 with agent-scope atomic loads) of query i are complete for the helpers of iteration i + 1, and the
+        // set that the helpers have just read is free for the walk of query i + 1.
         __syncthreads();
-        // ---------------- merge: thread = time step (in rounds of blockDim steps), then wave 0 scans the step sizes
-        auto count_bits = [&](int k, int t, int l) {   // count word of lane l's event of (wavefront k, step t)
-            if (!s_flag[(size_t)k * T + t]) return 0x3f800000u;
-            return __hip_atomic_load(reinterpret_cast<const uint32_t *>(counts_all) + ((size_t)k * T + t) * 64 + l,
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        auto step_total = [&](int t) {
-            uint32_t n = 0;
-            for (int k = 0; k < NW; ++k) n += (uint32_t)__builtin_popcountll(s_mask[(size_t)k * T + t]);
-            return n;
-        };
-        auto step_big = [&](int t) {       // count of the step's last event >= 2^23 (the step has events)
-            for (int k = NW - 1; k >= 0; --k) {
-                const uint64_t m = s_mask[(size_t)k * T + t];
-                if (m) return count_bits(k, t, 63 - __builtin_clzll(m)) >= 0x4b000000u;
-            }
-            return false;
-        };
-        for (int i = threadIdx.x; i < mixed_words; i += blockDim.x) s_mixed[i] = 0u;
-        if (threadIdx.x == 0) *s_any = 0u;
-        __syncthreads();
-        for (int t = threadIdx.x; t < T; t += blockDim.x) {
-            const uint32_t tot = step_total(t);
-            // an empty step that must be written as the event {0, -0.0f}: step 0, or after a count >= 2^23
-            const bool expl = tot == 0 && (t == 0 || (step_total(t - 1) != 0 && step_big(t - 1)));
-            s_tot[t] = tot;
-            s_pos[t + 1] = tot + (expl ? 1u : 0u);
-            bool flagged = false;
-            if (tot) for (int k = 0; k < NW; ++k) flagged |= s_flag[(size_t)k * T + t] != 0;
-            if (expl && t == 0) atomicOr(&s_mixed[0], 1u);            // at position 0: chunk 0 holds a count that is not 1
-            else if (expl || flagged) *s_any = 1u;
-        }
-        __syncthreads();
-        if (w == 0) {                      // prefix sum of the step sizes, 64 steps per round
-            uint32_t carry = 0;
-            for (int b = 0; b < T; b += 64) {
-                const int t = b + lane;
-                const uint32_t inc = wave_inclusive_sum((t < T) ? s_pos[t + 1] : 0u);
-                if (t < T) s_pos[t + 1] = carry + inc;          // inclusive: position after step t
-                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            }
-            if (lane == 0) s_pos[0] = 0u;
-        }
-        __syncthreads();
-        uint32_t *ev = a.events + (size_t)q * a.cap;
-        if (*s_any) {                      // (workgroup-uniform) chunks that hold a count other than 1: rare
-            for (int t = threadIdx.x; t < T; t += blockDim.x) {
-                uint32_t p = s_pos[t];
-                if (s_pos[t + 1] - p == 0) continue;
-                if (s_tot[t] == 0) { atomicOr(&s_mixed[(p >> 4) >> 5], 1u << ((p >> 4) & 31)); continue; }
-                for (int k = 0; k < NW; ++k) {
-                    const uint64_t m = s_mask[(size_t)k * T + t];
-                    if (s_flag[(size_t)k * T + t]) {
-                        uint32_t pe = p;
-                        for (uint64_t mm = m; mm; mm &= mm - 1, ++pe)
-                            if (count_bits(k, t, __builtin_ctzll(mm)) > 0x3f800000u) atomicOr(&s_mixed[(pe >> 4) >> 5], 1u << ((pe >> 4) & 31));
-                    }
-                    p += (uint32_t)__builtin_popcountll(m);
-                }
-            }
-            __syncthreads();
-        }
-        // one item per (step, walking wavefront): the events of that wavefront in that step, behind those of the lower ones
-        for (int i = threadIdx.x; i < T * NW; i += blockDim.x) {
-            const int t = i / NW, k = i - t * NW;
-            uint32_t p = s_pos[t];
-            if (s_pos[t + 1] - p == 0) continue;
-            // the step(s) that follow carry no spikes and are not written: flag on this step's LAST event
-            const bool empty_next = (t + 1 < T) && (s_pos[t + 2] - s_pos[t + 1] == 0);
-            auto put = [&](uint32_t pos, uint32_t w0, uint32_t w1) {
-                if ((pos & (EV_CHUNK - 1)) == 0 && ((s_mixed[(pos >> 4) >> 5] >> ((pos >> 4) & 31)) & 1u)) w0 |= EV_CHUNK_MIXED;
-                reinterpret_cast<uint2 *>(ev)[pos] = make_uint2(w0, w1);
-            };
-            const uint32_t tot = s_tot[t];
-            if (tot == 0) {                // explicit empty step
-                if (k == 0) put(p, 0u, EV_LAST | (empty_next ? EV_EMPTY_NEXT : 0u));
-                continue;
-            }
-            uint64_t m = s_mask[(size_t)k * T + t];
-            if (!m) continue;
-            const uint32_t last = p + tot - 1;
-            for (int j = 0; j < k; ++j) p += (uint32_t)__builtin_popcountll(s_mask[(size_t)j * T + t]);
-            const bool counted = s_flag[(size_t)k * T + t] != 0;      // counts above 1 in this (wavefront, step): rare
-            for (; m; m &= m - 1) {
-                const int l = __builtin_ctzll(m);
-                uint32_t w1 = counted ? count_bits(k, t, l) : 0x3f800000u;
-                if (p == last) w1 |= EV_LAST | ((empty_next && (w1 & 0x7fffffffu) < 0x4b000000u) ? EV_EMPTY_NEXT : 0u);
-                put(p, (uint32_t)(k * 64 + l) * (uint32_t)a.ev_scale, w1);
-                ++p;
-            }
-        }
-        const uint32_t count = s_pos[T];
-        const uint32_t pad = ((uint32_t)EV_CHUNK - (count & (EV_CHUNK - 1))) & (EV_CHUNK - 1);
-        if (threadIdx.x < pad) reinterpret_cast<uint2 *>(ev)[count + threadIdx.x] = make_uint2(0u, 0x3f800000u);
-        if (threadIdx.x == 0) a.nwords[q] = 2u * (count + pad);
-        // no barrier here: the next query's walk writes the other set of tables
     }
-    if (f < a.F) a.vfeat[(size_t)s * a.F + f] = v;
+    if (walker && f < a.F) a.vfeat[(size_t)s * a.F + f] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1751,7 +1775,7 @@ size_t fire_lds_bytes(int T, int F, int cap_words)
 {
     const size_t NW = (size_t)(F + 63) / 64;
     const size_t mixed_words = ((size_t)cap_words / EV_WORDS + 31) / 32;
-    return 2 * (((size_t)T * NW * 12 + 7) & ~(size_t)7) + (2 * (size_t)T + 1) * 4 + mixed_words * 4 + 16;
+    return 2 * (((size_t)T * NW * 12 + 7) & ~(size_t)7) + FIRE_HELPERS * ((2 * (size_t)T + 1) + mixed_words) * 4;
 }
 
 template <int PPL, bool W_LDS>
@@ -1971,7 +1995,7 @@ int lens_feature_currents(const uint8_t *d_frames, int Q, int HW, const int32_t 
     if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_currents) return LENS_ERR_NULL;
     if (Q < 0 || HW <= 0 || N <= 0 || T <= 0 || F <= 0 || ldw1 < F) return LENS_ERR_SIZE;
     if (ldc < F || (ldc & 63)) return LENS_ERR_SIZE;
-    if (N > 1024 || F > 64 * FIRE_MAX_WAVES) return LENS_ERR_UNSUPPORTED;
+    if (N > 1024 || F > 1024) return LENS_ERR_UNSUPPORTED;
     if (Q == 0) return LENS_OK;
     FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, nullptr, Q, 0, nullptr, 0, nullptr, 1, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
@@ -2007,7 +2031,7 @@ int lens_feature_fire(const float *d_currents, int ldc, int Q, int T, int F,
     FireArgs a{d_currents, ldc, Q, T, F, d_vfeat, n_streams, d_events, cap_words, d_nwords, ev_scale,
                static_cast<float *>(d_scratch)};
     if (int e = set_lds(k_feature_fire, lds)) return e;
-    hipLaunchKernelGGL(k_feature_fire, dim3(n_streams), dim3(FIRE_THREADS), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_feature_fire, dim3(n_streams), dim3((NW + FIRE_HELPERS) * 64), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

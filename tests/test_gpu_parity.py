@@ -489,7 +489,7 @@ def test_two_pass_carried_feature_layer_writes_identical_streams(O):
         c, frames, w1, w2, gt, G = load_config(tag)
         cases.append((w1, w2[:64], c["roi"], c["dims"], 250, frames[:40], 1))
     for dims, roi, F, T, dens, wscale, streams in [(5, 10, 157, 33, 255, 0.8, 1), (8, 16, 313, 250, 40, 0.3, 3),
-                                                   (3, 9, 40, 7, 255, 3.0, 1), (10, 20, 1024, 19, 90, 0.5, 2),
+                                                   (3, 9, 40, 7, 255, 3.0, 1), (10, 20, 768, 19, 90, 0.5, 2),
                                                    (6, 12, 64, 64, 2, 0.9, 1), (4, 8, 65, 100, 255, 1e9, 1)]:
         N = dims * dims
         w1 = (rng.standard_normal((F, N)) * wscale).astype(np.float32)

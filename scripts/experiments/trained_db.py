@@ -10,23 +10,12 @@ usage: trained_db.py [P] [epochs] [carry 0|1]
 """
 import os
 import sys
-import tempfile
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-
-
-def traverses(P, roi, seed=99):
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    rate = torch._standard_gamma(torch.full((P, roi, roi), 0.5), generator=g) * 6.0
-    ref = torch.poisson(rate, generator=g).clamp_(max=255).to(torch.uint8)
-    qry = torch.poisson(rate, generator=g).clamp_(max=255).to(torch.uint8)
-    return ref, qry
 
 
 def main():
@@ -34,29 +23,16 @@ def main():
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     carry = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
     import main as cli
-    from lens_amd.train_model import LENS_Trainer, training_inputs
     from lens_amd.engine import LensEngine, seqmatch_topk
+    from lens_amd.synthetic import synthetic_traverses, train_on_traverse
     roi, dims, T = 128, 10, 250
-    ref, qry = traverses(P, roi)
+    ref, qry = synthetic_traverses(P, roi)
     a = cli.build_parser().parse_args(["--train_model", "--reference_places", str(P), "--query_places", str(P),
                                        "--epoch_feat", str(epochs), "--epoch_out", str(epochs), "--roi_dim", str(roi)])
-    cwd = os.getcwd()
-    with tempfile.TemporaryDirectory() as tmp:
-        os.chdir(tmp)
-        try:
-            torch.manual_seed(0); np.random.seed(0)
-            model = LENS_Trainer(a)
-            x = training_inputs(ref, roi // dims)
-            labels = torch.arange(P)
-            t0 = time.time()
-            model.train_layer(x, labels, model.feature_layer, prev_layers=[])
-            model.train_layer(x, labels, model.output_layer, prev_layers=["feature_layer"])
-            torch.cuda.synchronize()
-            print(f"trained {P} places, {epochs} epochs per layer: {time.time() - t0:.2f} s", flush=True)
-        finally:
-            os.chdir(cwd)
-    w1 = model.feature_layer.w.weight.detach().contiguous()
-    w2 = model.output_layer.w.weight.detach().contiguous()
+    t0 = time.time()
+    w1, w2 = train_on_traverse(a, ref)
+    torch.cuda.synchronize()
+    print(f"trained {P} places, {epochs} epochs per layer: {time.time() - t0:.2f} s", flush=True)
     eng = LensEngine(w1, w2, roi, dims, T, device="cuda", max_batch=min(P, 4096))
     rows = []
     for c0 in range(0, P, 4096):

@@ -151,3 +151,30 @@ def test_cli_train_then_infer(tmp_path):
         assert len(R) == 6 and all(0.0 <= r <= 1.0 for r in R) and R[-1] >= R[0]
     finally:
         os.chdir(cwd)
+
+
+def test_trained_synthetic_database_recognises_its_places():
+    """Train -> infer -> match, end to end on synthetic places: a reference and a query traverse are two Poisson draws of
+    each place's rate image; both layers are trained on the reference traverse by the GPU trainer, the query traverse
+    goes through the inference kernels.  The oracle repeats the inference with the trained weights (counts and top-K
+    bit-identical), and the sequence matcher finds the right place for most queries (chance: 1/256)."""
+    import main as cli
+    from oracle import oracle as O
+    from lens_amd.engine import LensEngine, seqmatch_topk
+    from lens_amd.synthetic import synthetic_traverses, train_on_traverse
+    P, roi, dims, T = 256, 128, 10, 250
+    ref, qry = synthetic_traverses(P, roi)
+    a = cli.build_parser().parse_args(["--train_model", "--reference_places", str(P), "--query_places", str(P),
+                                       "--epoch_feat", "32", "--epoch_out", "32", "--roi_dim", str(roi)])
+    w1, w2 = train_on_traverse(a, ref)
+    eng = LensEngine(w1, w2, roi, dims, T, device="cuda", max_batch=P)
+    counts = eng.forward_counts(qry.cuda(), carry=False)
+    want = O.forward(qry.numpy(), dims, O.rand_U(T, roi * roi), w1.numpy(), w2.numpy(), carry=False)
+    assert np.array_equal(counts.cpu().numpy(), want)
+    idx, val = seqmatch_topk(counts, 2, 5)
+    oi, ov = O.topk(O.seqmatch(want, 2), 5)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(val.cpu().numpy(), ov)
+    truth = np.arange(oi.shape[0])
+    recall1 = float((oi[:, 0] == truth).mean())
+    print("Recall@1 after the sequence matcher:", recall1, " raw argmax:", float((want.argmax(1) == np.arange(P)).mean()))
+    assert recall1 >= 0.85

@@ -866,16 +866,28 @@ __device__ __forceinline__ void integrate_chunk(const uint32_t (&e)[EV_WORDS], c
     "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",      \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",      \
     "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",      \
-    "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+    "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99" LENS_OUT_JUMP_SGPRS
 #define LENS_OUT_V64_79 "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
 #define LENS_OUT_V80_95 "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
 #define LENS_OUT_V96_111                                                                                                 \
     "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
 #define LENS_OUT_V112_127                                                                                                \
     "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+// -DLENS_OUTPUT_JUMP: the operands of the computed-jump variant of the loop (gen_output_loop.py with LENS_GEN_JUMP=1;
+// measured slower than the loop with a test per event, kept as a reproducible experiment, not built by default)
+#ifdef LENS_OUTPUT_JUMP
+#define LENS_OUT_JUMP_OUT                                                                                                \
+    , [m] "=&s"(lastm), [x] "=&s"(jx), [bl] "=&s"(pc_lo), [bh] "=&s"(pc_hi), [vw] "=&v"(vwords), [va] "=&v"(vaddr)
+#define LENS_OUT_JUMP_IN , [voff] "v"(voff)
+#define LENS_OUT_JUMP_SGPRS , "s100", "s101"
+#else
+#define LENS_OUT_JUMP_OUT
+#define LENS_OUT_JUMP_IN
+#define LENS_OUT_JUMP_SGPRS
+#endif
 #define LENS_OUT_COMMON_OUT                                                                                              \
-    [soff] "+&s"(soff), [nch] "=&s"(nch), [t] "=&v"(t), [t2] "=&v"(t2), [sc] "=&s"(sc), [so] "=&s"(so)
-#define LENS_OUT_COMMON_IN [ev] "s"(ev), [nwp] "s"(nwords), [lane] "v"(lane_addr), [thr] "v"(thr)
+    [soff] "+&s"(soff), [nch] "=&s"(nch), [t] "=&v"(t), [t2] "=&v"(t2), [sc] "=&s"(sc), [so] "=&s"(so) LENS_OUT_JUMP_OUT
+#define LENS_OUT_COMMON_IN [ev] "s"(ev), [nwp] "s"(nwords), [lane] "v"(lane_addr), [thr] "v"(thr) LENS_OUT_JUMP_IN
 template <int PPL>
 __device__ __forceinline__ void output_loop_asm(const uint32_t *ev, const uint32_t *nwords, uint32_t lane_addr,
                                                 float (&v)[PPL], float (&cnt)[PPL])
@@ -884,6 +896,10 @@ __device__ __forceinline__ void output_loop_asm(const uint32_t *ev, const uint32
     uint32_t soff = 0, nch, sc, so;
     float a[PPL], t, t2;
     const float thr = 0.99999994f;   // 1 - 2^-24: the clip rounds it up to exactly 1.0
+#ifdef LENS_OUTPUT_JUMP
+    uint32_t lastm, jx, pc_lo, pc_hi, vwords, vaddr;
+    const uint32_t voff = (threadIdx.x & 15u) * 8u + 4u;   // byte offset of count word (lane & 15) in a chunk
+#endif
     if constexpr (PPL == 1) {
         asm volatile(
 #include "output_loop_p1.inc"
@@ -920,6 +936,9 @@ __device__ __forceinline__ void output_loop_asm(const uint32_t *ev, const uint32
 #undef LENS_OUT_V96_111
 #undef LENS_OUT_V112_127
 #undef LENS_OUT_COMMON_OUT
+#undef LENS_OUT_JUMP_OUT
+#undef LENS_OUT_JUMP_IN
+#undef LENS_OUT_JUMP_SGPRS
 #undef LENS_OUT_COMMON_IN
 
 template <int PPL, bool W_LDS>

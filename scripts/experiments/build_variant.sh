@@ -1,7 +1,8 @@
 #!/bin/bash
 # Build a kernel variant into variants/<name>.so from a scratch copy of the sources:
 #   scripts/experiments/build_variant.sh <name> [VAR=value ...]   (the variables reach the two generators)
-# Use with LENS_AMD_SO=variants/<name>.so (scripts/experiments/ab.sh).
+# Use with LENS_AMD_SO=variants/<name>.so (scripts/experiments/ab.sh).  EXTRA_HIPCC adds compiler flags, e.g.
+#   EXTRA_HIPCC=-DLENS_OUTPUT_JUMP scripts/experiments/build_variant.sh jump LENS_GEN_JUMP=1
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)

@@ -37,6 +37,12 @@ PAIR_FIRST = True               # a step's first two events enter the accumulato
 # Timing probes only (wrong results): LENS_GEN_PROBE=nowait drops the wait for the weight reads (how much of a chunk's
 # time is their exposed latency), =nolds drops the reads themselves.  Never set for a committed .inc file.
 PROBE = os.environ.get("LENS_GEN_PROBE", "")
+# Experiment, LENS_GEN_JUMP=1 (with -DLENS_OUTPUT_JUMP for lens_kernels.hip): chunks whose counts are all 1 take one
+# computed jump per time step instead of a test per event (jump_chunk).  Bit-exact, and measured slower: 61 % fewer
+# branch and 38 % more scalar instructions, +5.3 % time at the benchmark's density, +0.5 % on the bundled frames --
+# an s_setpc_b64 costs about as much as the ten not-taken test-and-branch pairs it replaces.  Never set for a committed file.
+JUMP = os.environ.get("LENS_GEN_JUMP", "0") == "1"
+COPY_STRIDE_LOG2 = 9            # byte stride of the 17 code copies a computed jump selects from
 
 
 def gen(ppl):
@@ -76,6 +82,107 @@ def gen(ppl):
             r.append(f"v_max_f32 %[t], %[t], {V[3]}")
         return r, "%[t]"
 
+    def jump_chunk(e, c, lab, W, cnt):
+        """Integration of a chunk whose counts are all 1, without a test per event.  The running sum of a step lives in
+        the weight registers themselves (body E<k>: w[k] += w[k-1]; a step's first event costs nothing), and the code
+        exists in 17 copies at a fixed byte stride: copy j is E0 .. Ej followed by the end of a step at event j, copy 16
+        is E0 .. E15 for a step that goes on in the next chunk ([a] carries its sum; E0 is w[0] += [a], with [a] = 0
+        after a step that ended with the chunk).  The end of step j finds the next LAST event j' in [m] (s_ff1) and
+        jumps to body E<j+2> of copy j' -- the new step starts at event j+1 -- so a step of n events costs n - 1 adds
+        per place, one spike test and ONE jump.  Same f32 operations in the same order as chains A / S."""
+        bs = 4 * ppl                                             # bytes of one body: ppl x v_add_f32_e32
+        assert (EV_CHUNK + 1) * bs + 160 <= (1 << COPY_STRIDE_LOG2)
+        copy0 = lab("COPY0")
+        # dispatch of the chunk's first step: always through E0 (adds the carried sum)
+        e(f"{lab('A0')}:")
+        e("s_ff1_i32_b32 %[x], %[m]")
+        e(f"s_lshl_b32 %[x], %[x], {COPY_STRIDE_LOG2}")
+        e(f"s_add_u32 %[x], %[x], {copy0}-ANCHOR_%=")
+        e("s_add_u32 s100, %[x], %[bl]")
+        e("s_addc_u32 s101, %[bh], 0")
+        e("s_setpc_b64 s[100:101]")
+        for j in range(EV_CHUNK + 1):
+            e(f".p2align {COPY_STRIDE_LOG2}")
+            if j == 0:
+                e(f"{copy0}:")
+            last = min(j, EV_CHUNK - 1)
+            for k in range(last + 1):
+                w = W(k)
+                for q in range(ppl):
+                    if k == 0:
+                        e(f"v_add_f32_e32 {w[q]}, {A[q]}, {w[q]}")
+                    elif j == EV_CHUNK and k == EV_CHUNK - 1:      # the open step's sum leaves the chunk in [a]
+                        e(f"v_add_f32_e32 {A[q]}, {W(k - 1)[q]}, {w[q]}")
+                    else:
+                        e(f"v_add_f32_e32 {w[q]}, {W(k - 1)[q]}, {w[q]}")
+            if j == EV_CHUNK:
+                break                                            # falls through into the chunk's tail
+            # ---- end of the step whose last event is j ----
+            w = W(j)
+            if j == EV_CHUNK - 1:
+                e(f"{lab('SE15')}:")
+            sal = []                                             # the jump's scalar chain, interleaved with the VALU work
+            if j < EV_CHUNK - 2:
+                sal = [f"s_and_b32 %[x], %[m], {hex(0x1ffff & ~((2 << j) - 1))}",
+                       "s_ff1_i32_b32 %[x], %[x]",
+                       f"s_lshl_b32 %[x], %[x], {COPY_STRIDE_LOG2}",
+                       f"s_add_u32 %[x], %[x], {copy0}-ANCHOR_%=+{(j + 2) * bs}",
+                       "s_add_u32 s100, %[x], %[bl]",
+                       "s_addc_u32 s101, %[bh], 0"]
+            mx, top = fire_max()
+            val = [f"v_add_f32_e32 {V[q]}, {V[q]}, {w[q]}" for q in range(ppl)] + mx + [f"v_cmp_le_f32 vcc, %[thr], {top}"]
+            val += [f"v_fma_f32 {A[q]}, {V[q]}, 0.5, 0.5 clamp" for q in range(ppl)]
+            for n in range(max(len(val), len(sal))):             # VALU instructions leave scc alone (s_add_u32 -> s_addc_u32)
+                if n < len(val):
+                    e(val[n])
+                if n < len(sal):
+                    e(sal[n])
+            e(f"s_cbranch_vccnz {lab(f'SPK{j}')}")
+            e(f"{lab(f'R{j}')}:")
+            for q in range(ppl):
+                e(f"v_fma_f32 {V[q]}, {A[q]}, 2.0, -1.0")
+            if j < EV_CHUNK - 2:
+                e("s_setpc_b64 s[100:101]")
+            elif j == EV_CHUNK - 2:
+                # event 15 is all that is left: a step of its own, or the start of a step that goes on in the next chunk
+                e(f"s_bitcmp1_b32 %[m], {EV_CHUNK - 1}")
+                e(f"s_cbranch_scc1 {lab('SE15')}")
+                for q in range(ppl):
+                    e(f"v_mov_b32 {A[q]}, {W(EV_CHUNK - 1)[q]}")
+                e(f"s_branch {lab('END')}")
+            else:
+                for q in range(ppl):
+                    e(f"v_mov_b32 {A[q]}, 0")
+                e(f"s_branch {lab('END')}")
+            spike_path(c, lab, j, "", cnt)
+
+    def spike_path(c, lab, i, m, cnt):
+        c(f"{lab(f'SPK{i}{m}')}:")
+        for k in range(ppl):
+            c(f"v_max_f32 %[t], 0, {V[k]}")      # a NaN membrane (never a signalling one: it is a sum) gives 0
+            c("v_floor_f32 %[t], %[t]")
+            c(f"v_sub_f32 {V[k]}, {V[k]}, %[t]")
+            c(f"v_add_f32 {C[k]}, {C[k]}, %[t]")
+        c(f"s_bitcmp0_b32 {cnt(i)}, 0")
+        c(f"s_cbranch_scc1 {lab(f'RC{i}{m}')}")
+        if m == "H":                            # the flag exists only on counts below 2^23
+            c(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
+            c("s_cmp_lt_u32 %[sc], 0x4b000000")
+            c(f"s_cbranch_scc0 {lab(f'RC{i}{m}')}")
+        # dropped empty steps follow: a membrane left at exactly 1.0 by the clip fires there
+        for k in range(ppl):
+            c(f"v_fma_f32 %[t], {V[k]}, 0.5, 0.5 clamp")
+            c("v_fma_f32 %[t], %[t], 2.0, -1.0")
+            c(f"v_add_f32 %[t2], 1.0, {C[k]}")
+            c("v_cmp_eq_f32 vcc, 1.0, %[t]")
+            c("s_nop 1")
+            c(f"v_cndmask_b32 {C[k]}, {C[k]}, %[t2], vcc")
+            c(f"v_cndmask_b32_e64 {V[k]}, {V[k]}, 0, vcc")
+        c(f"{lab(f'RC{i}{m}')}:")                # the membranes changed: redo the first half of the clip
+        for k in range(ppl):
+            c(f"v_fma_f32 {A[k]}, {V[k]}, 0.5, 0.5 clamp")
+        c(f"s_branch {lab(f'R{i}{m}')}")
+
     def chunk(buf, other, name):
         e = hot.append
         off = lambda i: f"s{buf + 2 * i}"
@@ -113,10 +220,20 @@ def gen(ppl):
         # word as it is; the others get a copy of the read phase that masks the flag off, behind the loop.
         e(f"s_bitcmp1_b32 {off(0)}, 31")
         e(f"s_cbranch_scc1 {lab('MIXED')}")
+        if JUMP:
+            # bit i of [m] = event i is the LAST of its step, from the chunk's count words as one lane-parallel compare
+            # (lane i holds count word i & 15; loaded one chunk ahead); bit 16 = sentinel "the step goes on in the next chunk"
+            e("s_waitcnt vmcnt(0)")
+            e("v_cmp_gt_i32 vcc, 0, %[vw]")
+            e("s_and_b32 %[m], vcc_lo, 0xffff")
+            e("s_or_b32 %[m], %[m], 0x10000")
         read_phase(e, off(0))
         e(f"s_cbranch_scc1 {lab('A0')}")
         e(f"s_load_dwordx16 s[{other}:{other + 15}], %[ev], %[soff] offset:0x0")
         e(f"s_load_dwordx16 s[{other + 16}:{other + 31}], %[ev], %[soff] offset:0x40")
+        if JUMP:
+            e("v_add_u32 %[va], %[soff], %[voff]")
+            e("global_load_dword %[vw], %[va], %[ev]")
         # A chunk with counts other than 1: is any of them 2^23 or more (mantissa LSB = data, not the EV_EMPTY_NEXT
         # flag)?  The OR of the 16 count words is below 0x4b000000 only if every count is (a few combinations of
         # counts from 2^21 up test positive as well and take the careful variant, which is correct for any chunk).
@@ -127,6 +244,9 @@ def gen(ppl):
         c(f"s_cbranch_scc1 {lab('NOPF')}")
         c(f"s_load_dwordx16 s[{other}:{other + 15}], %[ev], %[soff] offset:0x0")
         c(f"s_load_dwordx16 s[{other + 16}:{other + 31}], %[ev], %[soff] offset:0x40")
+        if JUMP:
+            c("v_add_u32 %[va], %[soff], %[voff]")
+            c("global_load_dword %[vw], %[va], %[ev]")       # overwrites this chunk's (unused) count words: loads return in order
         c(f"{lab('NOPF')}:")
         c(f"s_or_b32 %[sc], {cnt(0)}, {cnt(1)}")
         for i in range(2, EV_CHUNK):
@@ -143,6 +263,12 @@ def gen(ppl):
             # chunk's tail (-0.6 % same-box against a branch to it); everything else sits behind the loop
             e = warm.append if mixed else main
             al = lambda i: lab(f"A{i}{m}") if i < EV_CHUNK else lab("END")
+            if JUMP and not mixed:
+                jump_chunk(main, cold.append, lab, W, cnt)
+                main(f"{lab('END')}:")
+                main("s_waitcnt lgkmcnt(0)")          # the next chunk's words
+                main("s_cmp_eq_u32 %[nch], -1")          # wrapped around: that was the last chunk
+                continue
 
             def count_to_sc(i, back):      # [sc] = count of event i as a float (flag bits cleared)
                 e(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
@@ -232,33 +358,7 @@ def gen(ppl):
                             e(f"v_mov_b32 {A[k]}, 0")       # the step's successor is in the next chunk
                         e(f"s_branch {lab('END')}")
 
-                # spike path of step i
-                c = cold.append
-                c(f"{lab(f'SPK{i}{m}')}:")
-                for k in range(ppl):
-                    c(f"v_max_f32 %[t], 0, {V[k]}")      # a NaN membrane (never a signalling one: it is a sum) gives 0
-                    c("v_floor_f32 %[t], %[t]")
-                    c(f"v_sub_f32 {V[k]}, {V[k]}, %[t]")
-                    c(f"v_add_f32 {C[k]}, {C[k]}, %[t]")
-                c(f"s_bitcmp0_b32 {cnt(i)}, 0")
-                c(f"s_cbranch_scc1 {lab(f'RC{i}{m}')}")
-                if m == "H":                            # the flag exists only on counts below 2^23
-                    c(f"s_and_b32 %[sc], {cnt(i)}, 0x7ffffffe")
-                    c("s_cmp_lt_u32 %[sc], 0x4b000000")
-                    c(f"s_cbranch_scc0 {lab(f'RC{i}{m}')}")
-                # dropped empty steps follow: a membrane left at exactly 1.0 by the clip fires there
-                for k in range(ppl):
-                    c(f"v_fma_f32 %[t], {V[k]}, 0.5, 0.5 clamp")
-                    c("v_fma_f32 %[t], %[t], 2.0, -1.0")
-                    c(f"v_add_f32 %[t2], 1.0, {C[k]}")
-                    c("v_cmp_eq_f32 vcc, 1.0, %[t]")
-                    c("s_nop 1")
-                    c(f"v_cndmask_b32 {C[k]}, {C[k]}, %[t2], vcc")
-                    c(f"v_cndmask_b32_e64 {V[k]}, {V[k]}, 0, vcc")
-                c(f"{lab(f'RC{i}{m}')}:")                # the membranes changed: redo the first half of the clip
-                for k in range(ppl):
-                    c(f"v_fma_f32 {A[k]}, {V[k]}, 0.5, 0.5 clamp")
-                c(f"s_branch {lab(f'R{i}{m}')}")
+                spike_path(cold.append, lab, i, m, cnt)
 
 
     e = hot.append
@@ -268,6 +368,12 @@ def gen(ppl):
     e("s_load_dword %[nch], %[nwp], 0x0")
     e(f"s_load_dwordx16 s[{EA}:{EA + 15}], %[ev], %[soff] offset:0x0")
     e(f"s_load_dwordx16 s[{EA + 16}:{EA + 31}], %[ev], %[soff] offset:0x40")
+    if JUMP:
+        e("global_load_dword %[vw], %[voff], %[ev]")     # the first chunk's count words, lane i: word 2 * (i & 15) + 1
+        e("s_getpc_b64 s[100:101]")
+        e("ANCHOR_%=:")
+        e("s_mov_b32 %[bl], s100")
+        e("s_mov_b32 %[bh], s101")
     e("s_waitcnt lgkmcnt(0)")
     e(f"s_lshr_b32 %[nch], %[nch], {EV_CHUNK.bit_length()}")     # words -> chunks of 2 * EV_CHUNK words
     e("s_cmp_eq_u32 %[nch], 0")
@@ -279,7 +385,7 @@ def gen(ppl):
     chunk(EB, EA, "b")
     e("s_cbranch_scc0 LOOP_%=")
     e("s_branch DONE_%=")
-    tail = ["DONE_%=:"]
+    tail = ["DONE_%=:"] + (["s_waitcnt vmcnt(0)"] if JUMP else [])
     return hot + warm + cold + tail
 
 

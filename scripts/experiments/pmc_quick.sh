@@ -15,12 +15,16 @@ done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+per = collections.defaultdict(float)          # a counter is reported per XCD / shader engine: summed per dispatch
 for f in glob.glob(sys.argv[1] + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:60]
-        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = next((n for n in ("k_output_counts", "k_feature_events", "k_seqmatch_topk") if n in r["Kernel_Name"]), None)
+        if k:
+            per[(k, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+for (k, d, c), v in per.items():
+    acc[k][c].append(v)
 for k in acc:
-    if "k_output" in k or "k_feature" in k:
+    if True:
         print("==", k)
         for c in sorted(acc[k]):
             v = acc[k][c]

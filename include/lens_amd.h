@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 8
+#define LENS_AMD_ABI_VERSION 9
 
 /* Rows of slack behind the currents buffer of lens_feature_currents / lens_feature_fire. */
 #define LENS_FIRE_SLACK_ROWS 32
@@ -104,6 +104,13 @@ size_t lens_event_capacity_words(int T, int F);
  * walked by one wavefront of its own, so the width is chosen for the number of tiles resident at once rather than
  * for the cost per place.  (No counterpart in the reference: a property of this library's kernels.) */
 int lens_output_tile_places(int F, int P, int carry, int n_groups);
+
+/* 1 when lens_output_counts reads W2^T through L2 for these arguments instead of staging tiles in LDS: no tile fits
+ * (lens_output_tile_places == 0), or carried state with more (64-place tile, stream) wavefronts than the CUs' LDS holds
+ * tiles at once -- a carried stream is sequential in the query index, so rounds of LDS-resident tiles would add up, while
+ * through L2 every tile's wavefront is resident from the start (100 000 places, one stream: 13.1 -> 8.0 ms per 256
+ * queries).  The tile width and the event scale stay those of the 64-place LDS tile.  (No counterpart in the reference.) */
+int lens_output_reads_through_l2(int F, int P, int carry, int n_groups);
 
 /* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F, P, carry and split) can
  * consume its streams: the byte stride of one W2^T row in that tile (512 for the 128- and the 192-place tile,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "lens_build_threshold_codes": (_i, [_c_p, _i, _i, _c_p]),
     "lens_event_capacity_words": (ctypes.c_size_t, [_i, _i]),
     "lens_output_tile_places": (_i, [_i, _i, _i, _i]),
+    "lens_output_reads_through_l2": (_i, [_i, _i, _i, _i]),
     "lens_event_scale": (_i, [_i, _i, _i, _i]),
     "lens_build_active_steps": (_i, [_c_p, _i, _i, _c_p]),
     "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
@@ -59,7 +60,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class LensAmdError(RuntimeError):

@@ -738,6 +738,7 @@ struct OutArgs {
     int n_whole;     // batch mode: workgroups of the main part (whole rounds of the CUs), 0 = none
     int n_main;      // ... tiles per round of the main part
     int g_main;      // ... query groups per tile there (1: a workgroup takes a whole tile)
+    int row_mul;     // tiles read through L2: bytes of w2t per unit of an event's offset word (4 * ldw / event scale)
 };
 
 template <int PPL> struct VecT;
@@ -772,7 +773,7 @@ __device__ __forceinline__ void vec_unpack(const typename VecT<PPL>::type &x, fl
 // lgkmcnt(0) and wait for the prefetch too.
 template <int PPL, bool W_LDS>
 __device__ __forceinline__ void load_weights(const uint32_t (&e)[EV_WORDS], const unsigned char *smem, const float *w2t,
-                                             int ldw, int pl, uint32_t lane_off, float (&w)[EV_CHUNK][PPL])
+                                             int row_mul, int pl, uint32_t lane_off, float (&w)[EV_CHUNK][PPL])
 {
     static_assert(PPL != 3, "three places per lane exist in the assembly loop only");
 #pragma unroll
@@ -783,7 +784,7 @@ __device__ __forceinline__ void load_weights(const uint32_t (&e)[EV_WORDS], cons
         if constexpr (W_LDS) {
             wv = *reinterpret_cast<const vec_t *>(smem + (off + lane_off));
         } else {
-            wv = *reinterpret_cast<const vec_t *>(w2t + (size_t)off * ldw + pl);
+            wv = *reinterpret_cast<const vec_t *>(reinterpret_cast<const char *>(w2t + pl) + (size_t)off * (uint32_t)row_mul);
         }
         vec_unpack<PPL>(wv, w[i]);
     }
@@ -1068,7 +1069,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
                 for (int i = 0; i < EV_WORDS; ++i) ea[i] = ev[i];
                 const char *p = reinterpret_cast<const char *>(ev);   // chunk being integrated (byte pointer: the token adds unshifted)
                 for (int c = 0; c < nch; c += 2) {
-                    load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.ldw, pl, lane_off, w);
+                    load_weights<PPL, W_LDS>(ea, smem, a.w2t, a.row_mul, pl, lane_off, w);
                     p += EV_WORDS * 4;
                     const uint32_t *nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
                     if (c + 1 < nch) {
@@ -1078,7 +1079,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
                     if (ea[0] & EV_CHUNK_MIXED) integrate_chunk<PPL, false>(ea, w, v, cnt, acc);
                     else integrate_chunk<PPL, true>(ea, w, v, cnt, acc);
                     if (c + 1 >= nch) break;
-                    load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.ldw, pl, lane_off, w);
+                    load_weights<PPL, W_LDS>(eb, smem, a.w2t, a.row_mul, pl, lane_off, w);
                     p += EV_WORDS * 4;
                     nxt = reinterpret_cast<const uint32_t *>(p + weights_token<PPL>(w));
                     if (c + 2 < nch) {
@@ -1973,6 +1974,27 @@ int lens_output_tile_places(int F, int P, int carry, int n_groups)
     return 64 * output_ppl(F, P, carry, n_groups);
 }
 
+// Carried state, more (tile, stream) wavefronts than fit the CUs' LDS at once (three 50 KB tiles per CU at F = 200: 768):
+// the tiles are read through L2 instead, one round of wavefronts whatever the database size.  A carried stream is
+// sequential in the query index, so rounds of LDS-resident tiles add up (100 000 places: three), while a lone wavefront
+// that reads its 64-place rows through L2 takes 1.3-1.9 times the LDS time per query.  Measured, 256 queries, ms per batch,
+// LDS / L2: 47 tiles x 16 streams 0.72 / 0.79, 196 x 16: 1.65 / 0.86, 391 x 1: 4.90 / 6.26, 782 x 1: 8.75 / 7.04,
+// 1563 x 1: 13.1 / 8.0, 1563 x 16: 9.2 / 7.4 (128 places per wavefront through L2: slower than 64 everywhere).
+static bool output_carry_through_l2(int F, int P, int n_groups)
+{
+    if (output_ppl(F, P, 1, n_groups) != 1) return false;
+    const size_t tile_bytes = (size_t)F * 64 * 4;
+    const size_t per_cu = (size_t)LDS_BUDGET / (tile_bytes + 512);
+    const size_t resident = NUM_CUS * (per_cu < 1 ? 1 : per_cu > 32 ? 32 : per_cu);
+    const size_t waves = (((size_t)(P > 0 ? P : 1) + 63) / 64) * (size_t)(n_groups > 0 ? n_groups : 1);
+    return waves > resident;
+}
+
+int lens_output_reads_through_l2(int F, int P, int carry, int n_groups)
+{
+    return output_ppl(F, P, carry, n_groups) == 0 || (carry && output_carry_through_l2(F, P, n_groups));
+}
+
 int lens_event_scale(int F, int P, int carry, int n_groups)
 {
     const int ppl = output_ppl(F, P, carry, n_groups);
@@ -2128,7 +2150,12 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
         grid = n_whole + (ntiles - (n_whole / NUM_CUS) * n_main) * n_groups;
     }
     OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? 1 : 0,
-              d_counts, ldo, ntiles, n_whole, n_main, g_main};
+              d_counts, ldo, ntiles, n_whole, n_main, g_main, 4 * ldw2};   // row_mul: event scale 1 for the through-L2 tiles of wide layers
+    if (carry && output_carry_through_l2(F, P, n_groups)) {
+        // 64-place tiles as in LDS (same event scale), but every tile's wavefront resident at once: see output_carry_through_l2
+        a.row_mul = 4 * ldw2 / 256;
+        return launch_output<1, false>(a, threads, grid, st);
+    }
     switch (ppl) {
     case 4: return launch_output<4, true>(a, threads, grid, st);
     case 3: return launch_output<3, true>(a, threads, grid, st);

@@ -123,6 +123,31 @@ def test_multi_stream_carry_matches_oracle(O):
     assert np.array_equal(out, ref)
 
 
+def test_carried_tiles_through_l2_match_oracle(O):
+    """Carried state with more (64-place tile, stream) wavefronts than the CUs' LDS holds tiles: the output layer reads the
+    database through L2 (every wavefront resident at once).  51 tiles x 16 streams = 816 wavefronts > 768; counts equal
+    the oracle's run on each stream, and the carried state continues over a second call."""
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    P, S = 3230, 16
+    w2 = synthetic_database(w2p, P).numpy()
+    frames = synthetic_frames(3 * S, 128, seed=17)
+    eng = _engine(w1, w2, 128, 10)
+    assert not eng.reads_through_l2(carry=True)
+    eng.reset_state(n_streams=S)
+    assert eng.reads_through_l2(carry=True) and eng.tile_places(carry=True) == 64
+    out = eng.forward_counts(frames[:2 * S].cuda(), carry=True).cpu().numpy()
+    U = O.rand_U(250, 128 * 128)
+    f = frames.numpy()
+    ref = [O.forward(f[s * 2:(s + 1) * 2], 10, U, w1, w2, carry=True, skip_zero=True) for s in range(S)]
+    assert np.array_equal(out, np.concatenate(ref)) and out.sum() > 0
+    # second call: one more query per stream, on the carried state
+    out2 = eng.forward_counts(frames[2 * S:].cuda(), carry=True).cpu().numpy()
+    for s in range(S):
+        both = np.concatenate([f[s * 2:(s + 1) * 2], f[2 * S + s:2 * S + s + 1]])
+        assert np.array_equal(out2[s], O.forward(both, 10, U, w1, w2, carry=True, skip_zero=True)[2]), s
+
+
 def test_odd_sizes_and_wide_layers(O):
     """Ragged sizes: N=49 (one partial register), F=63, P=641 already covered by sunset; here a wide
     feature layer (F=520 -> 16 registers/lane rounds to the 32 variant) and N=144."""

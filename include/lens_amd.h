@@ -106,10 +106,11 @@ size_t lens_event_capacity_words(int T, int F);
 int lens_output_tile_places(int F, int P, int carry, int n_groups);
 
 /* 1 when lens_output_counts reads W2^T through L2 for these arguments instead of staging tiles in LDS: no tile fits
- * (lens_output_tile_places == 0), or carried state with more (64-place tile, stream) wavefronts than the CUs' LDS holds
- * tiles at once -- a carried stream is sequential in the query index, so rounds of LDS-resident tiles would add up, while
- * through L2 every tile's wavefront is resident from the start (100 000 places, one stream: 13.1 -> 8.0 ms per 256
- * queries).  The tile width and the event scale stay those of the 64-place LDS tile.  (No counterpart in the reference.) */
+ * (lens_output_tile_places == 0), or carried state with more (64-place tile, stream) wavefronts than the CUs' LDS surely
+ * holds tiles at once -- a carried stream is sequential in the query index, so rounds of LDS-resident tiles would add
+ * up, while through L2 every tile's wavefront is resident from the start (100 000 places, one stream: 13.1 -> 5.6 ms per
+ * 256 queries).  The tile width and the event scale stay those of the 64-place LDS tile.  Needs F * ldw2 * 4 < 2^32
+ * (LDS tiles otherwise).  (No counterpart in the reference.) */
 int lens_output_reads_through_l2(int F, int P, int carry, int n_groups);
 
 /* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F, P, carry and split) can

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("LENS_AMD_SO") or os.path.join(_PKG, "liblens_amd.so")
 SRC = os.path.join(_PKG, "csrc", "lens_kernels.hip")
 INCLUDES = [os.path.join(_PKG, "csrc", n)                            # textually included by SRC
-            for n in ("feature_loop_n2f4.inc", "fire_loop.inc", "output_loop_p1.inc", "output_loop_p2.inc", "output_loop_p3.inc",
+            for n in ("feature_loop_n2f4.inc", "fire_loop.inc", "carry_l2_loop.inc", "output_loop_p1.inc", "output_loop_p2.inc", "output_loop_p3.inc",
                       "output_loop_p4.inc")]
 HEADER = os.path.join(ROOT, "include", "lens_amd.h")
 

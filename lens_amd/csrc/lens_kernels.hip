@@ -1104,6 +1104,50 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// a5-a6, carried state with the database read through L2: one wavefront per (64-place tile, stream), no LDS tile, so
+// every tile of a large database is resident at once (three 50 KB LDS tiles per CU make 100 000 places three rounds of
+// 768 wavefronts, and the rounds of a sequential stream add up).  The lone wavefront runs at the latency of its own
+// chain; its chunk loop (scripts/gen_carry_loop.py) keeps the weight rows of four chunks in flight.  Tiling and event
+// scale are those of the 64-place LDS tile; the arithmetic is integrate_chunk's.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_output_carry_l2(OutArgs a)
+{
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x % a.ntiles, grp = blockIdx.x / a.ntiles;
+    const int qs = (int)(((long long)grp * a.Q) / a.n_groups), qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
+    const int place = tile * 64 + lane;                          // < ldw: the rows are zero padded to a multiple of 256
+    const float *wb = a.w2t + (size_t)tile * 64;
+    const uint32_t lane4 = (uint32_t)lane * 4u, voff = (uint32_t)(lane & 31) * 4u;
+    const uint32_t rm = (uint32_t)a.row_mul;
+    const float thr = 0.99999994f;                               // 1 - 2^-24: the clip rounds it up to exactly 1.0
+    float v = (place < a.P) ? a.vout[(size_t)grp * a.ldv + place] : 0.0f;
+    for (int q = qs; q < qe; ++q) {
+        const uint32_t *ev = a.events + (size_t)q * a.cap;
+        const uint32_t *nwp = a.nwords + q;
+        float cnt, acc, t, t2;
+        uint32_t va, w0, w1, w2, w3, nch, soff, sl, sn, sc, so, cw, m, k;
+        asm volatile(
+#include "carry_l2_loop.inc"
+            : [v0] "+&v"(v), [c0] "=&v"(cnt), [a0] "=&v"(acc), [t] "=&v"(t), [t2] "=&v"(t2), [va] "=&v"(va), [w0] "=&v"(w0),
+              [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [nch] "=&s"(nch), [soff] "=&s"(soff), [sl] "=&s"(sl),
+              [sn] "=&s"(sn), [sc] "=&s"(sc), [so] "=&s"(so), [cw] "=&s"(cw), [m] "=&s"(m), [k] "=&s"(k)
+            : [ev] "s"(ev), [nwp] "s"(nwp), [wb] "s"(wb), [lane4] "v"(lane4), [voff] "v"(voff), [rm] "s"(rm), [thr] "v"(thr)
+            : "memory", "vcc", "scc",
+              "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+              "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
+              "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
+              "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+              "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+              "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+              "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+              "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+              "v124", "v125", "v126", "v127");
+        if (place < a.P) a.counts[(size_t)q * a.ldo + place] = cnt;
+    }
+    if (place < a.P) a.vout[(size_t)grp * a.ldv + place] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // a5-a6, DENSE variant: the "descriptor x database GEMM" on the f32 matrix cores, for comparison with the
 // event-driven kernel above.  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf
 // chain, so accumulating the dense [32 queries x F] spike tile of one time step against [F x 32 places]
@@ -1974,20 +2018,25 @@ int lens_output_tile_places(int F, int P, int carry, int n_groups)
     return 64 * output_ppl(F, P, carry, n_groups);
 }
 
-// Carried state, more (tile, stream) wavefronts than fit the CUs' LDS at once (three 50 KB tiles per CU at F = 200: 768):
-// the tiles are read through L2 instead, one round of wavefronts whatever the database size.  A carried stream is
+// Carried state, more (tile, stream) wavefronts than the CUs' LDS surely holds tiles at once: the tiles are read
+// through L2 instead (k_output_carry_l2), one round of wavefronts whatever the database size.  A carried stream is
 // sequential in the query index, so rounds of LDS-resident tiles add up (100 000 places: three), while a lone wavefront
-// that reads its 64-place rows through L2 takes 1.3-1.9 times the LDS time per query.  Measured, 256 queries, ms per batch,
-// LDS / L2: 47 tiles x 16 streams 0.72 / 0.79, 196 x 16: 1.65 / 0.86, 391 x 1: 4.90 / 6.26, 782 x 1: 8.75 / 7.04,
-// 1563 x 1: 13.1 / 8.0, 1563 x 16: 9.2 / 7.4 (128 places per wavefront through L2: slower than 64 everywhere).
+// that keeps four chunks of 64-place rows in flight through L2 takes 15-19 us per query against 14.7 from LDS.
+// Measured, 256 queries, ms per batch, LDS / L2: 16 tiles x 1 stream 4.86 / 4.90, 47 x 16: 0.71 / 0.74, 196 x 16:
+// 1.65 / 0.84, 391 x 1: 4.86 / 5.04, 391 x 16: 2.74 / 1.69, 768 x 1: 7.24 / 5.16 (three 50 KB tiles on EVERY CU is more
+// than the dispatcher achieves), 1563 x 1: 13.1 / 5.6, 1563 x 16: 9.2 / 5.8.  Hence: LDS while one tile less than fits
+// per CU covers all wavefronts (512 at F = 200), through L2 beyond.
 static bool output_carry_through_l2(int F, int P, int n_groups)
 {
     if (output_ppl(F, P, 1, n_groups) != 1) return false;
+    // tuning override: LENS_AMD_CARRY_L2=1 / 0 forces the choice wherever 64-place tiles are used (read once)
+    static const int forced = [] { const char *e = getenv("LENS_AMD_CARRY_L2"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 1) return forced == 1;
     const size_t tile_bytes = (size_t)F * 64 * 4;
     const size_t per_cu = (size_t)LDS_BUDGET / (tile_bytes + 512);
-    const size_t resident = NUM_CUS * (per_cu < 1 ? 1 : per_cu > 32 ? 32 : per_cu);
+    const size_t safe = NUM_CUS * (per_cu <= 2 ? 1 : per_cu > 33 ? 32 : per_cu - 1);
     const size_t waves = (((size_t)(P > 0 ? P : 1) + 63) / 64) * (size_t)(n_groups > 0 ? n_groups : 1);
-    return waves > resident;
+    return waves > safe;
 }
 
 int lens_output_reads_through_l2(int F, int P, int carry, int n_groups)
@@ -2151,10 +2200,11 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     }
     OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? 1 : 0,
               d_counts, ldo, ntiles, n_whole, n_main, g_main, 4 * ldw2};   // row_mul: event scale 1 for the through-L2 tiles of wide layers
-    if (carry && output_carry_through_l2(F, P, n_groups)) {
+    if (carry && output_carry_through_l2(F, P, n_groups) && (unsigned long long)F * (unsigned long long)ldw2 * 4ull < (1ull << 32)) {   // 32-bit row offsets
         // 64-place tiles as in LDS (same event scale), but every tile's wavefront resident at once: see output_carry_through_l2
         a.row_mul = 4 * ldw2 / 256;
-        return launch_output<1, false>(a, threads, grid, st);
+        hipLaunchKernelGGL(k_output_carry_l2, dim3((unsigned)grid), dim3(64), 0, st, a);
+        return (int)hipGetLastError();
     }
     switch (ppl) {
     case 4: return launch_output<4, true>(a, threads, grid, st);

@@ -1,11 +1,11 @@
-"""Time of one carried stream of 256 queries (reference semantics) for several chunk sizes of the pipelined form."""
+"""Time of one carried stream of 256 queries (reference semantics) for several chunk sizes of the pipelined form; places = argv[1] (default 1000)."""
 import sys, time, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 import bench
 from lens_amd.engine import LensEngine, seqmatch_topk
 from lens_amd.synthetic import synthetic_frames, synthetic_database
 w1, w2p = bench.pretrained()
-eng = LensEngine(w1, synthetic_database(w2p, 1000), bench.ROI, bench.DIMS, bench.T_STEPS, device="cuda", max_batch=256)
+eng = LensEngine(w1, synthetic_database(w2p, int(sys.argv[1]) if len(sys.argv) > 1 else 1000), bench.ROI, bench.DIMS, bench.T_STEPS, device="cuda", max_batch=256)
 fr = synthetic_frames(256, bench.ROI, seed=1234).cuda()
 for ch in (8, 16, 24, 32, 64, 1 << 30):
     eng.CARRY_CHUNK = ch

@@ -56,11 +56,11 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     assert [L.lens_output_tile_places(200, p, 0, 0) for p in (64, 1000, 100000)] == [64, 128, 192]
     assert L.lens_output_tile_places(100, 100000, 0, 0) == 256 and L.lens_output_tile_places(700, 5, 0, 0) == 0
     assert L.lens_output_tile_places(200, 100000, 1, 1) == 64 and L.lens_event_scale(200, 100000, 1, 1) == 256
-    # carried state reads the database through L2 once its (64-place tile, stream) wavefronts outnumber the LDS-resident
-    # tiles (3 per CU at F = 200: 768); the batch mode never does for layers that fit a tile
+    # carried state reads the database through L2 once its (64-place tile, stream) wavefronts outnumber the tiles the
+    # CUs' LDS surely holds (one less than fits per CU: 2 x 256 at F = 200); the batch mode never does for layers that fit a tile
     rd = L.lens_output_reads_through_l2
-    assert [rd(200, p, 1, 1) for p in (1000, 49152, 49153, 100000)] == [0, 0, 1, 1]
-    assert [rd(200, 3000, 1, g) for g in (1, 16, 17)] == [0, 0, 1]
+    assert [rd(200, p, 1, 1) for p in (1000, 32768, 32769, 100000)] == [0, 0, 1, 1]
+    assert [rd(200, 3000, 1, g) for g in (1, 10, 11)] == [0, 0, 1]
     assert rd(200, 100000, 0, 0) == 0 and rd(700, 5, 0, 0) == 1 and rd(700, 5, 1, 1) == 1
 
 

@@ -71,6 +71,8 @@ def _odd_state(rng, n):
 @pytest.mark.parametrize("hot,n_cases,seed", [(True, 150, 20241), (False, 200, 20242)])
 def test_fixed_seed_fuzz_against_the_oracle(O, hot, n_cases, seed):
     from lens_amd.engine import LensEngine, seqmatch_topk
+    from lens_amd import _lib
+    L_ = _lib.lib()
     rng = np.random.default_rng(seed)
     for case in range(n_cases):
         dims, roi, T, w1, w2, frames = _case(rng, hot)
@@ -86,6 +88,7 @@ def test_fixed_seed_fuzz_against_the_oracle(O, hot, n_cases, seed):
         # carried state, starting from membranes that no earlier step could have left behind
         st = O.State(N, F, P)
         st.v2[:], st.v3[:] = _odd_state(rng, F), _odd_state(rng, P)
+        v2_0, v3_0 = st.v2.copy(), st.v3.copy()
         eng.reset_state()
         eng.v_feat.copy_(torch.from_numpy(st.v2).cuda()[None])
         eng.v_out.copy_(torch.from_numpy(st.v3).cuda()[None])
@@ -97,6 +100,22 @@ def test_fixed_seed_fuzz_against_the_oracle(O, hot, n_cases, seed):
         assert bad == 0, ("carry", tag)
         bad_o = _diff(_bits(eng.v_out.cpu().numpy()[0]), _bits(st.v3))
         assert bad_o == 0, ("v_out", tag)
+        if case % 3 == 0:
+            # the same run as S identical carried streams, enough of them that the output layer reads its 64-place tiles
+            # through L2 (k_output_carry_l2) instead of LDS: every stream must repeat the single stream's result
+            S = next((n for n in (130, 260, 520) if L_.lens_output_reads_through_l2(F, P, 1, n) and
+                      L_.lens_output_tile_places(F, P, 1, n) == 64), 0)
+            if S:
+                Qc = len(frames)
+                engs = LensEngine(w1, w2, roi, dims, T, device="cuda", max_batch=Qc * S)
+                engs.reset_state(n_streams=S)
+                engs.v_feat.copy_(torch.from_numpy(v2_0).cuda()[None].expand(S, -1))
+                engs.v_out.copy_(torch.from_numpy(v3_0).cuda()[None].expand(S, -1))
+                outs = engs.forward_counts(fr.repeat(S, 1, 1), carry=True).view(S, Qc, P)
+                assert bool((outs == outc[None]).all() if np.isfinite(refc).all() else
+                            _diff(outs.cpu().numpy(), np.broadcast_to(refc, (S, Qc, P))) == 0), ("carry through L2", tag, S)
+                assert _diff(_bits(engs.v_out.cpu().numpy()), _bits(np.broadcast_to(st.v3, (S, P)))) == 0, ("v_out through L2", tag)
+                del engs
         L = int(rng.choice([1, 2, 3]))
         if len(frames) >= L and P >= L and np.isfinite(refc).all():
             gi, gv = seqmatch_topk(outc, L, 25)

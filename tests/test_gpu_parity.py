@@ -125,7 +125,7 @@ def test_multi_stream_carry_matches_oracle(O):
 
 def test_carried_tiles_through_l2_match_oracle(O):
     """Carried state with more (64-place tile, stream) wavefronts than the CUs' LDS holds tiles: the output layer reads the
-    database through L2 (every wavefront resident at once).  51 tiles x 16 streams = 816 wavefronts > 768; counts equal
+    database through L2 (every wavefront resident at once).  51 tiles x 16 streams = 816 wavefronts > 512; counts equal
     the oracle's run on each stream, and the carried state continues over a second call."""
     from lens_amd.synthetic import synthetic_frames, synthetic_database
     w1, w2p = pretrained_example()
@@ -453,6 +453,21 @@ def test_stream_consumer_dropped_steps(O, F, P, tile):
         if carry:
             assert np.array_equal(eng.v_out.cpu().numpy()[0], v)
     assert ref[0, 0] != 0 or ref[3, 2] != 0
+    if tile:
+        # The carried run once more as 520 identical streams: more (64-place tile, stream) wavefronts than the CUs' LDS
+        # holds tiles, so the tiles are read through L2 by k_output_carry_l2 (its own assembly loop): every stream must
+        # repeat the single stream's counts and final state.
+        S = 520
+        engs = _engine(w1, w2, 1, 1, T=max(T, 4), max_batch=Q * S)
+        engs.reset_state(n_streams=S)
+        assert engs.reads_through_l2(carry=True) and engs.tile_places(True) == 64 and engs.event_scale(True) == eng.event_scale(True)
+        engs._workspace(Q * S)
+        engs.events[:Q * S].copy_(torch.from_numpy(words.view(np.int32)).repeat(S, 1))
+        engs.nwords[:Q * S].copy_(torch.from_numpy(nw).repeat(S))
+        engs.v_out.copy_(torch.from_numpy(v0).cuda()[None, :].expand(S, -1))
+        gots = engs.output_counts(Q * S, carry=True).cpu().numpy().reshape(S, Q, P)
+        assert np.array_equal(gots, np.broadcast_to(ref, (S, Q, P))), (F, P, "through L2")
+        assert np.array_equal(engs.v_out.cpu().numpy(), np.broadcast_to(v, (S, P)))
 
 
 def test_event_list_ingest_matches_oracle(O):

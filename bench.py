@@ -180,7 +180,7 @@ def recall_identity(idx, K_list=(1, 5, 25)):
 # Step time of ONE GPU at a per-rank database size (places incl. the halo row, 4096 queries, synthetic density), measured
 # with `bench.py --places <n>`: what each rank of a DB-sharded run is expected to take, the all-gather and merge being
 # overlapped with the next step's kernels.  A projection to compare the first multi-GPU measurement with, not a result.
-SINGLE_GPU_STEP_MS = {12501: 2.03, 25001: 3.78, 50001: 7.22, 100000: 13.95}
+SINGLE_GPU_STEP_MS = {12501: 2.02, 25001: 3.74, 50001: 7.22, 100000: 13.95}
 
 
 def expected_sharded_ms(places_per_rank, queries):

@@ -16,7 +16,9 @@
 // Reference lines each kernel replaces are cited in include/lens_amd.h.
 // Generated gfx950 assembly, included as asm statements: feature_loop_n2f4.inc (scripts/gen_feature_loop.py), the step
 // loop of k_feature_events for the 65..128-input / 129..256-feature instantiation, and output_loop_p{1..4}.inc
-// (scripts/gen_output_loop.py), the chunk loop of k_output_counts for the four LDS tile widths.  The per-weight
+// (scripts/gen_output_loop.py), the chunk loop of k_output_counts for the four LDS tile widths; fire_loop.inc
+// (scripts/gen_fire_loop.py), the step walk of k_feature_fire; carry_l2_loop.inc (scripts/gen_carry_loop.py), the chunk
+// loop of k_output_carry_l2.  The per-weight
 // sections of the training kernels are blocks of instructions written out in this file.  Every path also exists in
 // HIP C++ (other instantiations, the through-L2 variant), which documents the arithmetic.
 #include <hip/hip_runtime.h>

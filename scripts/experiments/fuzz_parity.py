@@ -5,6 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from lens_amd.engine import LensEngine, seqmatch, seqmatch_topk
+from lens_amd import _lib
 from oracle import oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -12,6 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"     # larger Q / P / T: several query groups, many tiles, long streams
 HOT = len(sys.argv) > 3 and sys.argv[3] == "hot"     # the shapes of the hand-scheduled loops: 65..128 inputs, 129..256 features
 t0 = time.time()
+n_l2 = 0
 for case in range(n_cases):
     dims = int(rng.integers(1, 12))
     k = int(rng.integers(1, 4))
@@ -64,6 +66,20 @@ for case in range(n_cases):
                     print("MISMATCH (streams)", dict(case=case, dims=dims, k=k, F=F, P=P, T=T, Q=Q, ns=ns, stream=si, rep=rep, w1s=w1s, w2s=w2s, dens=dens))
                     sys.exit(1)
         eng.reset_state()
+    # the whole batch as S identical carried streams, enough of them that the 64-place tiles are read through L2
+    # (k_output_carry_l2): every stream must repeat the single stream's counts (`ref` is the carried run's)
+    lib = _lib.lib()
+    S = next((n for n in (130, 260, 520) if lib.lens_output_reads_through_l2(F, P, 1, n) and
+              lib.lens_output_tile_places(F, P, 1, n) == 64 and n * Q <= 8192), 0)
+    if S:
+        engs = LensEngine(w1, w2, roi, dims, T, device="cuda", max_batch=Q * S)
+        engs.reset_state(S)
+        outs = engs.forward_counts(torch.from_numpy(frames).cuda().repeat(S, 1, 1), carry=True).cpu().numpy().reshape(S, Q, P)
+        if not np.array_equal(outs, np.broadcast_to(ref, (S, Q, P)), equal_nan=True):
+            print("MISMATCH (through L2)", dict(case=case, dims=dims, k=k, F=F, P=P, T=T, Q=Q, S=S, w1s=w1s, w2s=w2s, dens=dens))
+            sys.exit(1)
+        n_l2 += 1
+        del engs
     L = int(rng.choice([1, 2, 3]))
     if Q >= L and P >= L and np.isfinite(ref).all():
         S = O.seqmatch(ref, L)
@@ -81,4 +97,4 @@ for case in range(n_cases):
             sys.exit(1)
     if case % 10 == 9 or BIG:        # (a big case takes the oracle a minute or more: keep the log moving)
         print(f"  {case + 1} cases, {time.time() - t0:.0f} s", flush=True)
-print(f"{n_cases} cases ok in {time.time() - t0:.1f} s")
+print(f"{n_cases} cases ok in {time.time() - t0:.1f} s ({n_l2} of them also as many carried streams through L2)")

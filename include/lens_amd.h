@@ -13,10 +13,13 @@
  *   - return value: 0 = LENS_OK; negative = argument error (nothing was enqueued);
  *     positive = hipError_t of the failed launch.  Nothing throws across the boundary.
  *   - the entry points keep no state between calls except process-wide caches that are written once and
- *     never change a result: the tuning overrides LENS_AMD_OUTPUT_PPL / LENS_AMD_TRAIN_LPR (read from the
- *     environment at first use), two "kernel attributes checked" flags (atomic), and the per-device address
- *     of the scratch array of lens_forward_counts_static (behind a mutex).  Calls from several host threads are
- *     safe; work on one device is ordered by the streams the caller passes.
+ *     never change a result: the tuning overrides LENS_AMD_OUTPUT_PPL / LENS_AMD_OUTPUT_WHOLE / LENS_AMD_TRAIN_LPR
+ *     (read from the environment at first use), two "kernel attributes checked" flags (atomic), and the per-device
+ *     address of the scratch array of lens_forward_counts_static (behind a mutex).  The overrides of the carried-state
+ *     layout, LENS_AMD_CARRY_L2 and LENS_AMD_CARRY_SHARED, are read from the environment at every call (tests walk one
+ *     shape through every layout); they change lens_event_scale too, so they must not change between a stream's
+ *     producer and its consumer.  Calls from several host threads are safe; work on one device is ordered by the streams
+ *     the caller passes.
  *
  * Data layouts (row-major, last index fastest)
  *   frames      uint8  [Q][HW]            event-count frames (PNG pixels), HW = roi_dim*roi_dim
@@ -104,6 +107,19 @@ size_t lens_event_capacity_words(int T, int F);
  * walked by one wavefront of its own, so the width is chosen for the number of tiles resident at once rather than
  * for the cost per place.  (No counterpart in the reference: a property of this library's kernels.) */
 int lens_output_tile_places(int F, int P, int carry, int n_groups);
+
+/* How lens_output_counts lays the work out for these arguments (a property of this library's kernels, no counterpart in
+ * the reference): LENS_LAYOUT_BATCH (carry == 0: queries are independent, workgroups of 16 wavefronts share a tile),
+ * or, with carried state -- every stream sequential in its query index -- LENS_LAYOUT_LONE_LDS (one wavefront per
+ * (64-place tile, stream) with its own LDS copy of the tile), LENS_LAYOUT_LONE_L2 (the same wavefronts reading their rows
+ * through L2: all resident at once however large the database) or LENS_LAYOUT_SHARED (the batch mode's wide LDS tile
+ * shared by up to 16 streams, one wavefront each: many streams on a large database).  Chosen by a cost model of the
+ * measured time per query-step; lens_output_tile_places and lens_event_scale follow the choice. */
+#define LENS_LAYOUT_BATCH 0
+#define LENS_LAYOUT_LONE_LDS 1
+#define LENS_LAYOUT_LONE_L2 2
+#define LENS_LAYOUT_SHARED 3
+int lens_output_layout(int F, int P, int carry, int n_groups);
 
 /* 1 when lens_output_counts reads W2^T through L2 for these arguments instead of staging tiles in LDS: no tile fits
  * (lens_output_tile_places == 0), or carried state with more (64-place tile, stream) wavefronts than the CUs' LDS surely

@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(1024) k_feature_fire(FireArgs a)
 struct OutArgs {
     const uint32_t *events; int cap; const uint32_t *nwords; int Q;
     const float *w2t; int F; int P; int ldw;
-    float *vout; int ldv; int n_groups; int carry;
+    float *vout; int ldv; int n_groups; int carry;     // carry: 1 = one wavefront per (tile, stream), 2 = 16 streams per tile
     float *counts; int ldo;
     int ntiles;
     int n_whole;     // batch mode: workgroups of the main part (whole rounds of the CUs), 0 = none
@@ -969,7 +969,15 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
     int &s_next = *reinterpret_cast<int *>(book + (a.carry ? 0 : OUT_ORDER_MAX * 6));   // carried state: the book is this word only
 
     int tile, grp = 0, qs = 0, qe = a.Q;
-    if ((int)blockIdx.x < a.n_whole) {
+    bool active = true;
+    if (a.carry == 2) {
+        // carried state, shared tile: workgroup = (tile, 16 streams), wavefront w walks stream 16 * group + w in order
+        tile = blockIdx.x % a.ntiles;
+        grp = (blockIdx.x / a.ntiles) * 16 + wave;
+        active = grp < a.n_groups;
+        qs = active ? (int)(((long long)grp * a.Q) / a.n_groups) : 0;
+        qe = active ? (int)(((long long)(grp + 1) * a.Q) / a.n_groups) : 0;
+    } else if ((int)blockIdx.x < a.n_whole) {
         // a round of the main part = n_main tiles x g_main query groups = one workgroup per CU, group-major (neighbouring
         // workgroups, which land on different XCDs, share a group's queries); g_main = 1 where the tiles alone fill the CUs
         const int per_round = a.n_main * a.g_main, j = blockIdx.x % per_round;
@@ -985,7 +993,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         qs = (int)(((long long)grp * a.Q) / a.n_groups);
         qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
     }
-    if (a.carry && wave != 0) return;        // a carried stream is sequential: one wavefront per tile
+    if (a.carry == 1 && wave != 0) return;   // a carried stream is sequential: one wavefront per (tile, stream)
     const uint32_t lane_off = (uint32_t)lane * (PPL == 3 ? 8 : PPL * 4);
     {
         const int nq = qe - qs;
@@ -1037,7 +1045,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         for (int k = 0; k < PPL; ++k) v[k] = 0.0f;
         if (a.carry) {
 #pragma unroll
-            for (int k = 0; k < PPL; ++k) v[k] = (place[k] < a.P) ? a.vout[(size_t)grp * a.ldv + place[k]] : 0.0f;
+            for (int k = 0; k < PPL; ++k) v[k] = (active && place[k] < a.P) ? a.vout[(size_t)grp * a.ldv + place[k]] : 0.0f;
         }
         for (int it = 0;; ++it) {
             int q = qs + it;                       // carry: the one wavefront walks the run in order
@@ -1097,7 +1105,7 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
             for (int k = 0; k < PPL; ++k)
                 if (place[k] < a.P) o[place[k]] = cnt[k];
         }
-        if (a.carry) {
+        if (a.carry && active) {
 #pragma unroll
             for (int k = 0; k < PPL; ++k)
                 if (place[k] < a.P) a.vout[(size_t)grp * a.ldv + place[k]] = v[k];
@@ -1983,14 +1991,30 @@ size_t lens_event_capacity_words(int T, int F)
 // width (wider tiles spread the per-event scalar work and branches over more places; measured at 100 000 places:
 // 1.79 / 1 / 0.87 / 0.69 for 64 / 128 / 192 / 256).  A database of a few tiles runs as a single round of
 // workgroups, where the coarser (query, tile) items of the wide tiles balance worse: measured +7 % at 1000 places.
-// Carried state (carry != 0): a tile is walked by ONE wavefront (a workgroup of its own, with its own copy of the
-// tile in LDS), so what counts is how many tiles are resident at once -- 160 KiB / tile bytes per CU -- and how long
-// one wavefront alone takes per query, which grows slowly with the width (CARRY_REL, measured): time ~ rounds of
-// resident workgroups x that.
-static int output_ppl(int F, int P, int carry, int n_groups)
+// Carried state (carry != 0) has three layouts, chosen by a cost model in microseconds per query of a stream (every
+// stream is sequential in its query index, so what counts is the wall time of one query-step times the rounds of
+// workgroups; all figures measured at F = 200):
+//   LONE_LDS  one wavefront per (64-place tile, stream), a workgroup of its own with its own copy of the tile in LDS:
+//             14.7 us per query, as long as the CUs' LDS surely holds all of them at once (one tile less than fits per
+//             CU: three 50 KB tiles on EVERY CU is more than the dispatcher achieves; 768 tiles x 1 stream: 7.24 ms per
+//             256 queries instead of 3.9).  64-place tiles: a lone wavefront takes 15.9 / 18.5 / 23.4 us on a 64- / 128- /
+//             192-place tile, and the narrow one keeps the most tiles resident.
+//   LONE_L2   the same wavefronts reading their rows through L2 (k_output_carry_l2), all resident whatever the database
+//             size: 17-19 us per query up to ~1500 wavefronts, beyond that bound by L2 / Infinity Cache traffic
+//             (12 501 places: 6272 wavefronts 46 us, 50 176: 314 us; 100 000 places: 25 008 wavefronts 321 us).
+//   SHARED    the batch mode's wide LDS tile shared by up to 16 streams, one wavefront each (workgroup = tile x 16
+//             streams): a query-step costs what a wavefront's query costs in batch mode with that many wavefronts per
+//             SIMD (31.5 us at four on the 192-place tile), but 16 streams advance per tile staged -- the layout for
+//             several streams on a large database (100 000 places x 16 streams, ms per 256 queries: 5.14 as lone
+//             wavefronts through L2, 1.52 shared; x 4: 5.18 / 4.48; x 2: 5.51 / 8.56; 12 501 places x 32: 0.37 / 0.21;
+//             1000 places x 16: 0.28 on lone LDS tiles / 0.35 shared -- scripts/experiments/carry_layouts.py).
+// LENS_AMD_CARRY_L2=0/1 and LENS_AMD_CARRY_SHARED=0/1/2/3/4 force a choice (tuning and tests; read at every call).
+enum { OUT_BATCH = 0, OUT_LONE_LDS = 1, OUT_LONE_L2 = 2, OUT_SHARED = 3 };
+struct OutPlan { int ppl; int mode; };
+
+static int output_ppl_batch(int F, int P)
 {
-    static const struct { int ppl; double rel; double carry_rel; } widths[] = {
-        {4, 0.69, 1.50}, {3, 0.87, 1.27}, {2, 1.00, 1.00}, {1, 1.79, 0.86}};   // carry: 15.9 / 18.5 / 23.4 us per query for 64 / 128 / 192
+    static const struct { int ppl; double rel; } widths[] = {{4, 0.69}, {3, 0.87}, {2, 1.00}, {1, 1.79}};
     // tuning override: LENS_AMD_OUTPUT_PPL=1..4 forces that width wherever it fits (read once)
     static const int forced = [] { const char *e = getenv("LENS_AMD_OUTPUT_PPL"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 4 && (size_t)F * 64 * forced * 4 <= (size_t)LDS_BUDGET - 4096) return forced;
@@ -2001,49 +2025,73 @@ static int output_ppl(int F, int P, int carry, int n_groups)
         if (tile_bytes > (size_t)LDS_BUDGET - 4096) continue;
         const int pt = 64 * c.ppl;
         const size_t tiles = ((size_t)(P > 0 ? P : 1) + pt - 1) / pt;
-        double cost;
-        if (carry) {
-            const size_t per_cu = (size_t)LDS_BUDGET / (tile_bytes + 512);   // allocation granularity
-            const size_t resident = NUM_CUS * (per_cu < 1 ? 1 : per_cu > 32 ? 32 : per_cu);
-            const size_t wgs = tiles * (size_t)(n_groups > 0 ? n_groups : 1);
-            cost = (double)((wgs + resident - 1) / resident) * c.carry_rel;
-        } else {
-            cost = (double)tiles * pt * c.rel * (c.ppl >= 3 && tiles < 128 ? 1.07 : 1.0);
-        }
+        const double cost = (double)tiles * pt * c.rel * (c.ppl >= 3 && tiles < 128 ? 1.07 : 1.0);
         if (!best || cost < best_cost) { best = c.ppl; best_cost = cost; }
     }
     return best;
 }
+
+static OutPlan output_plan(int F, int P, int carry, int n_groups)
+{
+    if (!carry) return {output_ppl_batch(F, P), OUT_BATCH};
+    const size_t places = (size_t)(P > 0 ? P : 1), S = (size_t)(n_groups > 0 ? n_groups : 1);
+    const size_t tile1 = (size_t)F * 64 * 4;
+    if (tile1 > (size_t)LDS_BUDGET - 4096) return {0, OUT_LONE_LDS};     // no tile fits: 256 places per lone wavefront through L2
+    // read at every call (unlike the other overrides), so that a test can walk one shape through every layout
+    const char *env_l2 = getenv("LENS_AMD_CARRY_L2"), *env_shared = getenv("LENS_AMD_CARRY_SHARED");
+    const int force_l2 = env_l2 ? atoi(env_l2) : -1;
+    const int force_shared = env_shared ? atoi(env_shared) : -1;    // 0: never, 1: always (cheapest width), 2..4: always, that many places per lane
+    // lone wavefronts on 64-place tiles
+    const size_t per_cu = (size_t)LDS_BUDGET / (tile1 + 512);            // allocation granularity
+    const size_t safe = NUM_CUS * (per_cu <= 2 ? 1 : per_cu > 33 ? 32 : per_cu - 1);
+    const size_t waves = ((places + 63) / 64) * S;
+    bool l2 = waves > safe;
+    if (force_l2 == 0 || force_l2 == 1) l2 = force_l2 == 1;
+    OutPlan best{1, l2 ? OUT_LONE_L2 : OUT_LONE_LDS};
+    // through L2 the wavefronts share the caches' bandwidth: 167 KB of rows per wavefront and query at the benchmark's
+    // density, ~26 TB/s from L2 while the database fits the L2s, ~13 TB/s from the Infinity Cache beyond
+    const double per_wave = (double)F * (double)(((places + 255) / 256) * 256) * 4.0 <= 24.0e6 ? 0.0066 : 0.0128;
+    double best_cost = l2 ? (per_wave * (double)waves > 18.9 ? per_wave * (double)waves : 18.9)
+                          : 14.7 * (double)((waves + safe - 1) / safe);
+    if (force_shared == 0) return best;
+    // up to 16 streams on a shared wide tile: lone = one wavefront alone on the tile, busy = per wavefront at four per SIMD
+    // (busy: measured with 16 queries per stream and launch, the tile's staging included: 100 000 places x 16 streams 1.52 ms
+    // per 256 queries = 3 rounds x 31.7 us; 12 501 x 16 on 128-place tiles 0.364 ms = 22.7 us, x 32: 26 us)
+    static const struct { int ppl; double lone, busy; } shared[] = {{4, 28.0, 33.3}, {3, 23.4, 31.5}, {2, 18.5, 24.0}};
+    const size_t wpw = S < 16 ? S : 16;                                   // wavefronts per workgroup
+    for (const auto &c : shared) {
+        if ((size_t)F * 64 * c.ppl * 4 > (size_t)LDS_BUDGET - 4096) continue;
+        if (force_shared >= 2 && force_shared != c.ppl) continue;
+        const size_t pt = 64 * (size_t)c.ppl;
+        const size_t wgs = ((places + pt - 1) / pt) * ((S + 15) / 16);
+        const double per_simd = (double)((wpw + 3) / 4);
+        const double t = c.lone > c.busy * per_simd / 4.0 ? c.lone : c.busy * per_simd / 4.0;
+        const double cost = t * (double)((wgs + NUM_CUS - 1) / NUM_CUS);
+        // (a predicted gain below 10 % is within the model's error: the lone wavefronts stay)
+        if (force_shared >= 1 ? (best.mode != OUT_SHARED || cost < best_cost) : cost < (best.mode == OUT_SHARED ? 1.0 : 0.9) * best_cost) {
+            best = {c.ppl, OUT_SHARED};
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+static int output_ppl(int F, int P, int carry, int n_groups) { return output_plan(F, P, carry, n_groups).ppl; }
 
 int lens_output_tile_places(int F, int P, int carry, int n_groups)
 {
     return 64 * output_ppl(F, P, carry, n_groups);
 }
 
-// Carried state, more (tile, stream) wavefronts than the CUs' LDS surely holds tiles at once: the tiles are read
-// through L2 instead (k_output_carry_l2), one round of wavefronts whatever the database size.  A carried stream is
-// sequential in the query index, so rounds of LDS-resident tiles add up (100 000 places: three), while a lone wavefront
-// that keeps four chunks of 64-place rows in flight through L2 takes 15-19 us per query against 14.7 from LDS.
-// Measured, 256 queries, ms per batch, LDS / L2: 16 tiles x 1 stream 4.86 / 4.90, 47 x 16: 0.71 / 0.74, 196 x 16:
-// 1.65 / 0.84, 391 x 1: 4.86 / 5.04, 391 x 16: 2.74 / 1.69, 768 x 1: 7.24 / 5.16 (three 50 KB tiles on EVERY CU is more
-// than the dispatcher achieves), 1563 x 1: 13.1 / 5.6, 1563 x 16: 9.2 / 5.8.  Hence: LDS while one tile less than fits
-// per CU covers all wavefronts (512 at F = 200), through L2 beyond.
-static bool output_carry_through_l2(int F, int P, int n_groups)
+int lens_output_layout(int F, int P, int carry, int n_groups)
 {
-    if (output_ppl(F, P, 1, n_groups) != 1) return false;
-    // tuning override: LENS_AMD_CARRY_L2=1 / 0 forces the choice wherever 64-place tiles are used (read once)
-    static const int forced = [] { const char *e = getenv("LENS_AMD_CARRY_L2"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || forced == 1) return forced == 1;
-    const size_t tile_bytes = (size_t)F * 64 * 4;
-    const size_t per_cu = (size_t)LDS_BUDGET / (tile_bytes + 512);
-    const size_t safe = NUM_CUS * (per_cu <= 2 ? 1 : per_cu > 33 ? 32 : per_cu - 1);
-    const size_t waves = (((size_t)(P > 0 ? P : 1) + 63) / 64) * (size_t)(n_groups > 0 ? n_groups : 1);
-    return waves > safe;
+    return output_plan(F, P, carry, n_groups).mode;
 }
 
 int lens_output_reads_through_l2(int F, int P, int carry, int n_groups)
 {
-    return output_ppl(F, P, carry, n_groups) == 0 || (carry && output_carry_through_l2(F, P, n_groups));
+    const OutPlan pl = output_plan(F, P, carry, n_groups);
+    return pl.ppl == 0 || pl.mode == OUT_LONE_L2;
 }
 
 int lens_event_scale(int F, int P, int carry, int n_groups)
@@ -2143,14 +2191,18 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     if (carry && n_groups <= 0) n_groups = 1;
     if (carry && n_groups > Q) return LENS_ERR_SIZE;
 
-    const int ppl = output_ppl(F, P, carry, n_groups);
+    const OutPlan plan = output_plan(F, P, carry, n_groups);
+    const int ppl = plan.ppl;
     const int pt = 64 * (ppl ? ppl : 4);
     const int ntiles = (P + pt - 1) / pt;
 
     // Batch mode: whole tiles for as many full rounds of the CUs as there are (a workgroup = one tile x all queries), the
     // remaining tiles split into query groups (see the kernel).  An explicit n_groups > 0 splits every tile that way.
     int threads, grid, n_whole = 0, n_main = NUM_CUS, g_main = 1;
-    if (carry) {
+    if (carry && plan.mode == OUT_SHARED) {
+        threads = 64 * (n_groups < 16 ? n_groups : 16);
+        grid = ntiles * ((n_groups + 15) / 16);
+    } else if (carry) {
         threads = 64;
         grid = ntiles * n_groups;
     } else {
@@ -2200,10 +2252,10 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
         if (n_groups > Q) n_groups = Q;
         grid = n_whole + (ntiles - (n_whole / NUM_CUS) * n_main) * n_groups;
     }
-    OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? 1 : 0,
+    OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? (plan.mode == OUT_SHARED ? 2 : 1) : 0,
               d_counts, ldo, ntiles, n_whole, n_main, g_main, 4 * ldw2};   // row_mul: event scale 1 for the through-L2 tiles of wide layers
-    if (carry && output_carry_through_l2(F, P, n_groups) && (unsigned long long)F * (unsigned long long)ldw2 * 4ull < (1ull << 32)) {   // 32-bit row offsets
-        // 64-place tiles as in LDS (same event scale), but every tile's wavefront resident at once: see output_carry_through_l2
+    if (carry && plan.mode == OUT_LONE_L2 && (unsigned long long)F * (unsigned long long)ldw2 * 4ull < (1ull << 32)) {   // 32-bit row offsets
+        // 64-place tiles as in LDS (same event scale), but every tile's wavefront resident at once: see output_plan
         a.row_mul = 4 * ldw2 / 256;
         hipLaunchKernelGGL(k_output_carry_l2, dim3((unsigned)grid), dim3(64), 0, st, a);
         return (int)hipGetLastError();

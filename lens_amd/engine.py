@@ -154,6 +154,11 @@ class LensEngine:
         """Places per LDS weight tile of the output kernel in this mode (0: weights read through L2)."""
         return int(_lib.lib().lens_output_tile_places(self.F, self.P, int(bool(carry)), self.n_streams if carry else 0))
 
+    def layout(self, carry=False):
+        """lens_output_layout for this mode: 0 batch, 1 lone wavefronts on LDS tiles, 2 lone wavefronts through L2,
+        3 wide LDS tiles shared by 16 carried streams."""
+        return int(_lib.lib().lens_output_layout(self.F, self.P, int(bool(carry)), self.n_streams if carry else 0))
+
     def reads_through_l2(self, carry=False):
         """True when the output layer reads the database through L2 instead of LDS tiles in this mode: no tile fits, or
         carried state with more (tile, stream) wavefronts than LDS-resident tiles (lens_output_reads_through_l2)."""

@@ -61,6 +61,12 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     rd = L.lens_output_reads_through_l2
     assert [rd(200, p, 1, 1) for p in (1000, 32768, 32769, 100000)] == [0, 0, 1, 1]
     assert [rd(200, 3000, 1, g) for g in (1, 10, 11)] == [0, 0, 1]
+    # the three carried layouts (1 lone wavefronts on LDS tiles, 2 through L2, 3 wide tiles shared by 16 streams)
+    lay = L.lens_output_layout
+    assert lay(200, 100000, 0, 0) == 0 and [lay(200, 100000, 1, g) for g in (1, 2, 4, 16)] == [2, 2, 3, 3] and lay(200, 12501, 1, 4) == 2
+    assert [lay(200, 1000, 1, g) for g in (1, 16, 32, 64)] == [1, 1, 1, 2] and lay(200, 12501, 1, 32) == 3
+    assert L.lens_output_tile_places(200, 100000, 1, 16) == 192 and L.lens_event_scale(200, 100000, 1, 16) == 512
+    assert L.lens_output_tile_places(200, 12501, 1, 32) == 128 and lay(700, 5, 1, 4) == 1
     assert rd(200, 100000, 0, 0) == 0 and rd(700, 5, 0, 0) == 1 and rd(700, 5, 1, 1) == 1
 
 

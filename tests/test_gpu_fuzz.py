@@ -2,6 +2,8 @@
 membrane states compared as float32 bit patterns, tolerance 0), plus sampled parity at sizes the oracle cannot
 run whole: real spike density against a 20 000-place database, and training of a 100 000-row output layer.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -116,6 +118,24 @@ def test_fixed_seed_fuzz_against_the_oracle(O, hot, n_cases, seed):
                             _diff(outs.cpu().numpy(), np.broadcast_to(refc, (S, Qc, P))) == 0), ("carry through L2", tag, S)
                 assert _diff(_bits(engs.v_out.cpu().numpy()), _bits(np.broadcast_to(st.v3, (S, P)))) == 0, ("v_out through L2", tag)
                 del engs
+        if case % 3 == 1:
+            # ... and as 20 identical streams on the wide LDS tiles that carried streams share 16 at a time (forced: the
+            # cost model picks that layout only for many streams on large databases)
+            os.environ["LENS_AMD_CARRY_SHARED"] = "1"
+            try:
+                if L_.lens_output_layout(F, P, 1, 20) == 3:
+                    S, Qc = 20, len(frames)
+                    engs = LensEngine(w1, w2, roi, dims, T, device="cuda", max_batch=Qc * S)
+                    engs.reset_state(n_streams=S)
+                    engs.v_feat.copy_(torch.from_numpy(v2_0).cuda()[None].expand(S, -1))
+                    engs.v_out.copy_(torch.from_numpy(v3_0).cuda()[None].expand(S, -1))
+                    outs = engs.forward_counts(fr.repeat(S, 1, 1), carry=True).view(S, Qc, P)
+                    assert bool((outs == outc[None]).all() if np.isfinite(refc).all() else
+                                _diff(outs.cpu().numpy(), np.broadcast_to(refc, (S, Qc, P))) == 0), ("carry, shared tiles", tag)
+                    assert _diff(_bits(engs.v_out.cpu().numpy()), _bits(np.broadcast_to(st.v3, (S, P)))) == 0, ("v_out, shared tiles", tag)
+                    del engs
+            finally:
+                os.environ.pop("LENS_AMD_CARRY_SHARED", None)
         L = int(rng.choice([1, 2, 3]))
         if len(frames) >= L and P >= L and np.isfinite(refc).all():
             gi, gv = seqmatch_topk(outc, L, 25)

@@ -148,6 +148,29 @@ def test_carried_tiles_through_l2_match_oracle(O):
         assert np.array_equal(out2[s], O.forward(both, 10, U, w1, w2, carry=True, skip_zero=True)[2]), s
 
 
+def test_carried_streams_on_shared_tiles_match_oracle(O):
+    """Many carried streams on a database of many tiles: the batch mode's wide LDS tile is shared by 16 streams, one
+    wavefront each walking its stream in order (12 tiles x 13 groups of streams here; the last group holds 8).  Counts
+    equal the oracle's run on each stream, and the carried state continues over a second call."""
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    P, S = 1500, 200
+    w2 = synthetic_database(w2p, P).numpy()
+    frames = synthetic_frames(3 * S, 128, seed=23)
+    eng = _engine(w1, w2, 128, 10)
+    eng.reset_state(n_streams=S)
+    assert eng.layout(carry=True) == 3 and eng.tile_places(carry=True) == 128 and not eng.reads_through_l2(carry=True)
+    out = eng.forward_counts(frames[:2 * S].cuda(), carry=True).cpu().numpy()
+    U = O.rand_U(250, 128 * 128)
+    f = frames.numpy()
+    ref = [O.forward(f[s * 2:(s + 1) * 2], 10, U, w1, w2, carry=True, skip_zero=True) for s in range(S)]
+    assert np.array_equal(out, np.concatenate(ref)) and out.sum() > 0
+    out2 = eng.forward_counts(frames[2 * S:].cuda(), carry=True).cpu().numpy()
+    for s in range(0, S, 7):
+        both = np.concatenate([f[s * 2:(s + 1) * 2], f[2 * S + s:2 * S + s + 1]])
+        assert np.array_equal(out2[s], O.forward(both, 10, U, w1, w2, carry=True, skip_zero=True)[2]), s
+
+
 def test_odd_sizes_and_wide_layers(O):
     """Ragged sizes: N=49 (one partial register), F=63, P=641 already covered by sunset; here a wide
     feature layer (F=520 -> 16 registers/lane rounds to the 32 variant) and N=144."""
@@ -453,21 +476,49 @@ def test_stream_consumer_dropped_steps(O, F, P, tile):
         if carry:
             assert np.array_equal(eng.v_out.cpu().numpy()[0], v)
     assert ref[0, 0] != 0 or ref[3, 2] != 0
-    if tile:
-        # The carried run once more as 520 identical streams: more (64-place tile, stream) wavefronts than the CUs' LDS
-        # holds tiles, so the tiles are read through L2 by k_output_carry_l2 (its own assembly loop): every stream must
-        # repeat the single stream's counts and final state.
-        S = 520
+    if not tile:
+        return
+
+    # The carried run once more in every other layout the library has for carried state, as S identical streams: each
+    # must repeat the single stream's counts and final state.
+    def replay(S, layout, places):
         engs = _engine(w1, w2, 1, 1, T=max(T, 4), max_batch=Q * S)
         engs.reset_state(n_streams=S)
-        assert engs.reads_through_l2(carry=True) and engs.tile_places(True) == 64 and engs.event_scale(True) == eng.event_scale(True)
+        assert (engs.layout(True), engs.tile_places(True)) == (layout, places), (F, P, S, engs.layout(True), engs.tile_places(True))
         engs._workspace(Q * S)
-        engs.events[:Q * S].copy_(torch.from_numpy(words.view(np.int32)).repeat(S, 1))
-        engs.nwords[:Q * S].copy_(torch.from_numpy(nw).repeat(S))
+        enc_w = np.zeros((Q, engs.cap), dtype=np.uint32)
+        enc_n = np.zeros(Q, dtype=np.int32)
+        for q, steps in enumerate(queries):
+            enc = _encode_stream(steps, engs.event_scale(True))
+            enc_w[q, :enc.size] = enc
+            enc_n[q] = enc.size
+        engs.events[:Q * S].copy_(torch.from_numpy(enc_w.view(np.int32)).repeat(S, 1))
+        engs.nwords[:Q * S].copy_(torch.from_numpy(enc_n).repeat(S))
         engs.v_out.copy_(torch.from_numpy(v0).cuda()[None, :].expand(S, -1))
         gots = engs.output_counts(Q * S, carry=True).cpu().numpy().reshape(S, Q, P)
-        assert np.array_equal(gots, np.broadcast_to(ref, (S, Q, P))), (F, P, "through L2")
-        assert np.array_equal(engs.v_out.cpu().numpy(), np.broadcast_to(v, (S, P)))
+        assert np.array_equal(gots, np.broadcast_to(ref, (S, Q, P))), (F, P, S, layout, places)
+        assert np.array_equal(engs.v_out.cpu().numpy(), np.broadcast_to(v, (S, P))), (F, P, S, layout, places)
+
+    # 520 streams: more (64-place tile, stream) wavefronts than the CUs' LDS holds tiles -> read through L2 (k_output_carry_l2)
+    replay(520, 2, 64)
+    import os
+    saved = {k: os.environ.get(k) for k in ("LENS_AMD_CARRY_L2", "LENS_AMD_CARRY_SHARED")}
+    try:
+        os.environ["LENS_AMD_CARRY_SHARED"], os.environ["LENS_AMD_CARRY_L2"] = "0", "1"
+        replay(1, 2, 64)                                   # a single stream through L2
+        os.environ["LENS_AMD_CARRY_L2"] = "0"
+        replay(3, 1, 64)                                   # lone wavefronts on LDS tiles, three streams
+        for ppl in (2, 3, 4):                              # wide tiles shared by up to 16 streams: every assembly loop
+            if F * 64 * ppl * 4 <= 160 * 1024 - 4096:
+                os.environ["LENS_AMD_CARRY_SHARED"] = str(ppl)
+                replay(1, 3, 64 * ppl)
+                replay(20, 3, 64 * ppl)                    # two groups of streams: 16 wavefronts + 4 (12 idle)
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
 
 
 def test_event_list_ingest_matches_oracle(O):

@@ -482,9 +482,15 @@ def main():
                     # the instruction-issue view: vector instructions per launch (committed PMC pass of this workload) over
                     # THIS run's launch time and the SIMDs' issue rate
                     roof["valu_issue_frac"] = pm["SQ_INSTS_VALU"] / (N_SIMD * avg_ms[dom] * 1e6 * VALU_ISSUE_PER_NS)
+                if dom == 1 and all(pm.get(k) for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE")):
+                    # the SIMD's issue port: one instruction per cycle, a wave64 vector instruction holds it for two.
+                    # Cycles of the PROFILED launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs), all counters of that pass.
+                    slots = 2.0 * pm["SQ_INSTS_VALU"] + pm["SQ_INSTS_SALU"] + pm["SQ_INSTS_BRANCH"] + pm["SQ_INSTS_LDS"] + pm.get("SQ_INSTS_SMEM", 0.0)
+                    roof["issue_port_frac"] = slots / (N_SIMD * pm["GRBM_GUI_ACTIVE"] / 8.0)
                 roof["offline_profile"] = dict(pm, note="rocprofv3 --pmc passes of this workload committed under "
                                                "profiles/ (not measured in this run); valu_issue_frac = SQ_INSTS_VALU "
-                                               "/ (1024 SIMDs x launch time x 1.2 VALU/ns)")
+                                               "/ (1024 SIMDs x launch time x 1.2 VALU/ns); issue_port_frac = (2 x VALU + SALU "
+                                               "+ branch + LDS + SMEM instructions) / (1024 SIMDs x cycles of the profiled launch)")
         cfg = 2 if a.places == 1000 else (3 if world == 1 else (4 if shard == "db" else 3))
         line = {
             "metric": "query event-frames/sec vs ref-DB size; Recall@1 parity with reference",

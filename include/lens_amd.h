@@ -215,7 +215,10 @@ int lens_feature_fire(const float *d_currents, int ldc, int Q, int T, int F,
  * d_w2t: [F][ldw2] with ldw2 % 256 == 0, ldw2 >= P, 16-byte aligned, padding columns zero
  *        (a database shard is simply a column range of this matrix).
  * n_groups / carry: as n_streams / carry of lens_feature_events (the two calls must use the same
- *        split).  carry != 0: d_vout [n_groups][ldv] carried state, read and written.
+ *        split, and the streams must have been written with lens_event_scale of the same F, P, carry and split).
+ *        carry != 0: d_vout [n_groups][ldv] carried state, read and written; the work is laid out as
+ *        lens_output_layout says (lone wavefronts per tile and stream on LDS tiles or through L2, or wide LDS tiles
+ *        shared by 16 streams): same results, bit for bit.
  * d_counts: float [Q][ldo], ldo >= P; columns >= P are not written.
  * cap_words: words between two queries' streams, a multiple of 32 and >= 32 (whole 32-word chunks are read, the
  *        first one of every query before its length is known); d_nwords[q] <= cap_words.

@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"     # larger Q / P / T: several query groups, many tiles, long streams
 HOT = len(sys.argv) > 3 and sys.argv[3] == "hot"     # the shapes of the hand-scheduled loops: 65..128 inputs, 129..256 features
 t0 = time.time()
-n_l2 = 0
+n_l2 = n_shared = 0
 for case in range(n_cases):
     dims = int(rng.integers(1, 12))
     k = int(rng.integers(1, 4))
@@ -80,6 +80,22 @@ for case in range(n_cases):
             sys.exit(1)
         n_l2 += 1
         del engs
+    # ... and as 20 identical streams on the wide LDS tiles that carried streams share 16 at a time (layout forced, width
+    # by turns: the cost model picks it only for many streams on large databases)
+    os.environ["LENS_AMD_CARRY_SHARED"] = str(1 + case % 4)
+    try:
+        if lib.lens_output_layout(F, P, 1, 20) == 3 and 20 * Q <= 8192:
+            engs = LensEngine(w1, w2, roi, dims, T, device="cuda", max_batch=Q * 20)
+            engs.reset_state(20)
+            outs = engs.forward_counts(torch.from_numpy(frames).cuda().repeat(20, 1, 1), carry=True).cpu().numpy().reshape(20, Q, P)
+            if not np.array_equal(outs, np.broadcast_to(ref, (20, Q, P)), equal_nan=True):
+                print("MISMATCH (shared tiles)", dict(case=case, dims=dims, k=k, F=F, P=P, T=T, Q=Q, w1s=w1s, w2s=w2s, dens=dens,
+                                                        tile=engs.tile_places(True)))
+                sys.exit(1)
+            n_shared += 1
+            del engs
+    finally:
+        os.environ.pop("LENS_AMD_CARRY_SHARED", None)
     L = int(rng.choice([1, 2, 3]))
     if Q >= L and P >= L and np.isfinite(ref).all():
         S = O.seqmatch(ref, L)
@@ -97,4 +113,4 @@ for case in range(n_cases):
             sys.exit(1)
     if case % 10 == 9 or BIG:        # (a big case takes the oracle a minute or more: keep the log moving)
         print(f"  {case + 1} cases, {time.time() - t0:.0f} s", flush=True)
-print(f"{n_cases} cases ok in {time.time() - t0:.1f} s ({n_l2} of them also as many carried streams through L2)")
+print(f"{n_cases} cases ok in {time.time() - t0:.1f} s ({n_l2} of them also as many carried streams through L2, {n_shared} as 20 streams on shared tiles)")

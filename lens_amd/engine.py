@@ -266,6 +266,8 @@ class LensEngine:
         return out
 
     CARRY_CHUNK = 16    # queries per launch of the pipelined carried stream (8: +4 %, 32: +2 %, 64: +10 % per 256 queries)
+    CARRY_FIRST = 4     # ... of the first launch, doubling from there up to CARRY_CHUNK (the output layer idles until the first
+                        # chunk's streams exist; 100 000 places: 5.87 -> 5.65 ms per 256 queries, 1000 places 4.86 -> 4.85)
 
     def _carried_stream_pipelined(self, frames, out):
         """One carried stream (the reference's semantics): both layers are sequential in the query index, each a
@@ -298,8 +300,12 @@ class LensEngine:
             if two_pass:                # the input currents of the whole call, in parallel, ahead of the sequential walk
                 with torch.cuda.stream(side):
                     self._feature_currents(frames, cur)
-            for k, c0 in enumerate(range(0, Q, self.CARRY_CHUNK)):
-                c1 = min(Q, c0 + self.CARRY_CHUNK)
+            starts, size = [], min(self.CARRY_FIRST, self.CARRY_CHUNK)
+            while not starts or starts[-1][1] < Q:                    # chunk sizes double from CARRY_FIRST up to CARRY_CHUNK
+                c0 = starts[-1][1] if starts else 0
+                starts.append((c0, min(Q, c0 + size)))
+                size = min(2 * size, self.CARRY_CHUNK)
+            for k, (c0, c1) in enumerate(starts):
                 fr, ev, nw = frames[c0:c1], self.events[c0:c1], self.nwords[c0:c1]
                 done = self._side_done[k & 1]
                 with torch.cuda.stream(side):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 9
+#define LENS_AMD_ABI_VERSION 10
 
 /* Rows of slack behind the currents buffer of lens_feature_currents / lens_feature_fire. */
 #define LENS_FIRE_SLACK_ROWS 32
@@ -178,7 +178,10 @@ int lens_feature_events(const uint8_t *d_frames, int Q, int HW,
  *
  * Pass 1, all queries in parallel.  Replaces lens/src/dataset.py:99-127 (raster), lens/run_model.py:130-137,141
  * (centre-pixel Conv2d + IAF #1) and the Linear of :143:
- *     d_currents[q][t][f] = ascending-n chain of fmaf(x[n], w1[f][n], acc) from +0,   float [Q][T][ldc],
+ *     I[q][t][f] = ascending-n chain of fmaf(x[n], w1[f][n], acc) from +0,
+ *     stored with the four steps of a group side by side (lens_feature_fire fetches them with one 16-byte load):
+ *     d_currents float [Q][T4 / 4][ldc][4], T4 = T rounded up to a multiple of 4 (steps T..T4-1 are written as zeros),
+ *     16-byte aligned; I[q][t][f] sits at ((q * T4 / 4 + t / 4) * ldc + f) * 4 + t % 4.
  *     ldc >= F and a multiple of 64 (columns F..ldc-1 are written as zeros).  N <= 1024, F <= 1024.
  *     lens_feature_fire prefetches ahead: allocate LENS_FIRE_SLACK_ROWS more rows of ldc floats behind the last
  *     query (never written, contents irrelevant).

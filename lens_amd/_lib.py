@@ -61,7 +61,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class LensAmdError(RuntimeError):

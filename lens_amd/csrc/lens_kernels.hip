@@ -449,7 +449,8 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_events(F
 //           four helper wavefronts expand the masks into the spike stream: per-step totals, a prefix sum for the
 //           positions, the LAST / EMPTY_NEXT / CHUNK_MIXED flags and explicit empty steps exactly as the one-pass
 //           writer of k_feature_events produces them (the streams are bit-identical); one barrier per query.
-//           The currents buffer carries FIRE_DEPTH rows of slack behind its last query: the walk prefetches that far.
+//           The currents are stored [q][t / 4][ldc][4], so that the walk fetches four steps of a feature with one 16-byte
+//           load; the buffer carries FIRE_DEPTH rows of slack behind its last query: the walk prefetches that far.
 // ------------------------------------------------------------------------------------------
 template <int NPL, int FPL, bool USE_LDS>
 __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_currents(FeatArgs a, float *__restrict__ cur, int ldc)
@@ -480,40 +481,50 @@ __global__ void __launch_bounds__((feat_threads<NPL, FPL>())) k_feature_currents
         const int n = i * 64 + lane;
         px[i] = (n < a.N) ? (uint32_t)a.frames[(size_t)q * a.HW + a.sel[n]] : 0u;
     }
-    float *out = cur + (size_t)q * a.T * ldc;
-    for (int t = 0; t < a.T; ++t) {
-        float acc[FPL];
+    // layout [q][t / 4][ldc][4]: the four steps of a group side by side, so that the walk of pass 2 fetches a feature's
+    // currents of four steps with one 16-byte load
+    const int T4 = (a.T + 3) & ~3;
+    float *out = cur + (size_t)q * T4 * ldc;
+    for (int t0 = 0; t0 < a.T; t0 += 4) {
+        float acc[4][FPL];
 #pragma unroll
-        for (int j = 0; j < FPL; ++j) acc[j] = 0.0f;
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = t0 + tt;
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-            uint32_t code;
-            if constexpr (USE_LDS) {
-                code = s_codes[t * NP + i * 64 + lane];
-            } else {
-                const int n = i * 64 + lane;
-                code = (n < a.N) ? (uint32_t)a.codes[(size_t)t * a.N + n] : 255u;
-            }
-            uint64_t m = __ballot(px[i] >= code);
-            while (m) {   // active inputs in ascending n (wave-uniform loop)
-                const int n = i * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+            for (int j = 0; j < FPL; ++j) acc[tt][j] = 0.0f;
+            if (t >= a.T) continue;                 // (wave-uniform) the last group of a T that is not a multiple of 4
 #pragma unroll
-                for (int j = 0; j < FPL; ++j) {
-                    float w;
-                    if constexpr (USE_LDS) {
-                        w = s_w[n * FP + j * 64 + lane];
-                    } else {
-                        const int f = j * 64 + lane;
-                        w = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+            for (int i = 0; i < NPL; ++i) {
+                uint32_t code;
+                if constexpr (USE_LDS) {
+                    code = s_codes[t * NP + i * 64 + lane];
+                } else {
+                    const int n = i * 64 + lane;
+                    code = (n < a.N) ? (uint32_t)a.codes[(size_t)t * a.N + n] : 255u;
+                }
+                uint64_t m = __ballot(px[i] >= code);
+                while (m) {   // active inputs in ascending n (wave-uniform loop)
+                    const int n = i * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+#pragma unroll
+                    for (int j = 0; j < FPL; ++j) {
+                        float w;
+                        if constexpr (USE_LDS) {
+                            w = s_w[n * FP + j * 64 + lane];
+                        } else {
+                            const int f = j * 64 + lane;
+                            w = (f < a.F) ? a.w1t[(size_t)n * a.ldw + f] : 0.0f;
+                        }
+                        acc[tt][j] = acc[tt][j] + w;   // == fmaf(1.0f, w, acc): the input spike is exactly 1
                     }
-                    acc[j] = acc[j] + w;   // == fmaf(1.0f, w, acc): the input spike is exactly 1
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < FPL; ++j)
-            if (j * 64 < ldc) out[(size_t)t * ldc + j * 64 + lane] = acc[j];
+            if (j * 64 < ldc)
+                *reinterpret_cast<float4 *>(out + ((size_t)(t0 >> 2) * ldc + j * 64 + lane) * 4) =
+                    make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
     }
 }
 
@@ -688,7 +699,7 @@ __global__ void __launch_bounds__(1024) k_feature_fire(FireArgs a)
             uint64_t *s_mask = reinterpret_cast<uint64_t *>(smem + set);                        // [NW][T]
             uint32_t *s_flag = reinterpret_cast<uint32_t *>(smem + set + (size_t)NW * T * 8);   // [NW][T]
             for (int t = lane; t < T; t += 64) { s_mask[(size_t)w * T + t] = 0ull; s_flag[(size_t)w * T + t] = 0u; }
-            const float *row0 = a.cur + (size_t)q * T * a.ldc;              // wave-uniform
+            const float *row0 = a.cur + (size_t)q * ((T + 3) & ~3) * a.ldc;   // wave-uniform; [q][t / 4][ldc][4]
             const float *sc = counts_sets + ((size_t)(it & 1) * NW + w) * ((size_t)T * 64);
             uint64_t hot = ~0ull;         // lanes whose membrane is exactly 1.0; all ones: step 0 always runs
             uint32_t tab = lds0 + (uint32_t)(set + ((size_t)w * T) * 8);
@@ -698,8 +709,8 @@ __global__ void __launch_bounds__(1024) k_feature_fire(FireArgs a)
             asm volatile(
 #include "fire_loop.inc"
                 : [v] "+&v"(v), [hot] "+&s"(hot), [tab] "+&v"(tab), [flg] "+&v"(flg)
-                : [ptr] "s"(row0), [sc] "s"(sc), [off] "v"((uint32_t)f * 4u), [lane4] "v"((uint32_t)lane * 4u),
-                  [ldc4] "s"((uint32_t)a.ldc * 4u), [T] "s"(T)
+                : [ptr] "s"(row0), [sc] "s"(sc), [off] "v"((uint32_t)f * 16u), [lane4] "v"((uint32_t)lane * 4u),
+                  [ldc4] "s"((uint32_t)a.ldc * 16u), [T] "s"(T)
                 : "memory", "vcc", "scc",
                   "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
                   "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
@@ -2135,6 +2146,7 @@ int lens_feature_currents(const uint8_t *d_frames, int Q, int HW, const int32_t 
     if (!d_frames || !d_sel || !d_codes || !d_w1t || !d_currents) return LENS_ERR_NULL;
     if (Q < 0 || HW <= 0 || N <= 0 || T <= 0 || F <= 0 || ldw1 < F) return LENS_ERR_SIZE;
     if (ldc < F || (ldc & 63)) return LENS_ERR_SIZE;
+    if ((uintptr_t)d_currents & 15) return LENS_ERR_ALIGN;          // 16-byte stores / loads of four steps
     if (N > 1024 || F > 1024) return LENS_ERR_UNSUPPORTED;
     if (Q == 0) return LENS_OK;
     FeatArgs a{d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, nullptr, Q, 0, nullptr, 0, nullptr, 1, nullptr, nullptr};
@@ -2163,7 +2175,7 @@ int lens_feature_fire(const float *d_currents, int ldc, int Q, int T, int F,
     if (ev_scale < 1 || (long long)ev_scale * F > 0x7fffffffLL) return LENS_ERR_SIZE;
     if (n_streams <= 0) n_streams = 1;
     if (n_streams > Q && Q > 0) return LENS_ERR_SIZE;
-    if ((uintptr_t)d_scratch & 3) return LENS_ERR_ALIGN;
+    if (((uintptr_t)d_scratch & 3) || ((uintptr_t)d_currents & 15)) return LENS_ERR_ALIGN;
     const int NW = (F + 63) / 64;
     const size_t lds = fire_lds_bytes(T, F, cap_words);
     if (NW > FIRE_MAX_WAVES || T >= (1 << 22) || lds > (size_t)LDS_BUDGET - 1024) return LENS_ERR_UNSUPPORTED;

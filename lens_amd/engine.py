@@ -176,8 +176,9 @@ class LensEngine:
     def _carried_buffers(self, Q):
         if self._cur is None or self._cur.shape[0] < Q:
             # lens_feature_fire prefetches 32 rows ahead: that much slack behind the last query (one more query of rows)
-            self._cur_store = torch.empty(((Q + 1) * self.T + 32, self.ldc), dtype=torch.float32, device=self.device)
-            self._cur = self._cur_store[:Q * self.T].view(Q, self.T, self.ldc)
+            t4 = (self.T + 3) // 4 * 4                       # layout [q][t / 4][ldc][4]: a query takes T4 rows of ldc floats
+            self._cur_store = torch.empty(((Q + 1) * t4 + 32, self.ldc), dtype=torch.float32, device=self.device)
+            self._cur = self._cur_store[:Q * t4].view(Q, t4, self.ldc)
         need = int(_lib.lib().lens_feature_fire_scratch_bytes(self.T, self.F, self.n_streams))
         if self._fire_scratch is None or self._fire_scratch.numel() < need:
             self._fire_scratch = torch.empty((need,), dtype=torch.uint8, device=self.device)

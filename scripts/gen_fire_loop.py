@@ -7,27 +7,29 @@ Why assembly: a carried stream is ONE workgroup with one wavefront per SIMD, so 
 instruction chain, and a branch costs a lone wavefront ~20 cycles.  As compiled from C++ a quiet step takes five
 branches; here a quiet step is one taken branch, a step with current and no spike two branches that fall through.
 
-Per step d of a group of DEPTH steps (currents I[d] prefetched DEPTH steps ahead into a ring of registers):
-    wait for I[d]
+The currents are laid out [t / 4][feature][4]: one 16-byte load per lane fetches a feature's currents of four steps.
+Per step d of DEPTH unrolled steps (currents I[d] prefetched DEPTH steps ahead into a ring of registers, four per load):
+    wait for I[d] (at the first step of its four)
     no lane has current and no membrane sits at exactly 1.0  ->  skip (the step is the identity on clip outputs)
     vm = v + I[d];  h = clamp(fma(vm, 0.5, 0.5));  some lane >= 1 - 2^-24 ?  -> FIRE (out of line)
     v = fma(h, 2, -1)                                                            (the clip, iaf_clip)
-    prefetch I[d] of step t + DEPTH
+    (after the fourth step of a load) prefetch the four currents DEPTH steps ahead
 FIRE: s = floor(max(vm, 0)); vm -= s; v = clip(vm); hot = lanes with v == 1.0; the step's spike mask (64 bits) goes to
 the wavefront's row of the LDS table, one 8-byte entry per step (pre-zeroed).  Counts above 1 (rare) also store the
 64 counts of the step to the wavefront's scratch row and set the step's flag word; that path drains the prefetches.
 Same f32 operations in the same order as iaf_update_fast() in lens_kernels.hip: bit-identical to the one-pass kernel.
 
 Operands: [v] membrane (in/out); [hot] SGPR pair, lanes at exactly 1.0 (in: -1 = step 0 always runs; out);
-[ptr] SGPR pair: address of row 0 of the query's currents; [off] lane's byte offset in a row; [lane4] 4 x lane; [ldc4] row
-stride in bytes; [tab] LDS byte address of the wavefront's mask entry of step 0 (in/out, advanced); [flg] LDS byte address
+[ptr] SGPR pair: address of the query's currents; [off] 16 x the lane's feature; [lane4] 4 x lane; [ldc4] bytes of a
+group of four steps (16 x ldc); [tab] LDS byte address of the wavefront's mask entry of step 0 (in/out, advanced); [flg] LDS byte address
 of its flag word of step 0 (in/out, advanced); [sc] SGPR pair: the wavefront's scratch rows [T][64] floats; [T] steps.
-Rows T .. T+DEPTH-1 of the currents are read (and ignored): the buffer carries DEPTH rows of slack.
+Up to DEPTH steps behind the query's last are read (and ignored): the buffer carries DEPTH rows of slack.
 Clobbers: v[64:64+DEPTH-1] (the ring), v[96:99], s[36:51], vcc, scc.
 """
 import os
 
 DEPTH = 32
+GROUP = 4                      # steps whose currents sit side by side in memory: one 16-byte load per lane
 RING = 64                      # first VGPR of the ring
 VM, H, A0, A1 = 96, 97, 98, 99
 S_N, S_T, S_G = 36, 37, 38     # steps left in the tail group, first step of the current group, full groups left
@@ -50,7 +52,8 @@ def gen():
             if checked:
                 e(f"s_cmp_le_u32 s{S_N}, {d}")
                 e(f"s_cbranch_scc1 DONE_%=")
-            e(f"s_waitcnt vmcnt({DEPTH - 1})")
+            if d % GROUP == 0:
+                e(f"s_waitcnt vmcnt({DEPTH // GROUP - 1})")               # the 16-byte load of this group of four steps
             e(f"v_cmp_neq_f32_e32 vcc, 0, {I}")
             e(f"s_or_b64 s[{S_TMP}:{S_TMP + 1}], vcc, %[hot]")          # scc = some current, or some membrane at 1.0
             e(f"s_cbranch_scc0 {L('NEXT')}")
@@ -61,9 +64,11 @@ def gen():
             e(f"v_fma_f32 %[v], v{H}, 2.0, -1.0")
             e(f"s_mov_b64 %[hot], 0")
             e(f"{L('NEXT')}:")
-            e(f"global_load_dword {I}, %[off], s[{S_PTR}:{S_PTR + 1}]")                   # step t + DEPTH into the ring slot just consumed
-            e(f"s_add_u32 s{S_PTR}, s{S_PTR}, %[ldc4]")
-            e(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
+            if d % GROUP == GROUP - 1:                                  # steps t + DEPTH - 3 .. t + DEPTH into the four ring registers just consumed
+                g0 = RING + d - (GROUP - 1)
+                e(f"global_load_dwordx4 v[{g0}:{g0 + GROUP - 1}], %[off], s[{S_PTR}:{S_PTR + 1}]")
+                e(f"s_add_u32 s{S_PTR}, s{S_PTR}, %[ldc4]")
+                e(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
 
             c = cold.append
             c(f"{L('FIRE')}:")
@@ -94,9 +99,9 @@ def gen():
 
     e(f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[ptr]")
     e(f"s_mov_b64 s[{S_SC}:{S_SC + 1}], %[sc]")
-    # ring fill: steps 0 .. DEPTH-1 (rows beyond T-1 exist as slack)
-    for d in range(DEPTH):
-        e(f"global_load_dword v{RING + d}, %[off], s[{S_PTR}:{S_PTR + 1}]")
+    # ring fill: steps 0 .. DEPTH-1 (steps beyond T-1 exist as slack)
+    for d in range(0, DEPTH, GROUP):
+        e(f"global_load_dwordx4 v[{RING + d}:{RING + d + GROUP - 1}], %[off], s[{S_PTR}:{S_PTR + 1}]")
         e(f"s_add_u32 s{S_PTR}, s{S_PTR}, %[ldc4]")
         e(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
     e(f"s_mov_b32 s{S_T}, 0")

@@ -125,13 +125,16 @@ int lens_output_layout(int F, int P, int carry, int n_groups);
  * (lens_output_tile_places == 0), or carried state with more (64-place tile, stream) wavefronts than the CUs' LDS surely
  * holds tiles at once -- a carried stream is sequential in the query index, so rounds of LDS-resident tiles would add
  * up, while through L2 every tile's wavefront is resident from the start (100 000 places, one stream: 13.1 -> 5.6 ms per
- * 256 queries).  The tile width and the event scale stay those of the 64-place LDS tile.  Needs F * ldw2 * 4 < 2^32
- * (LDS tiles otherwise).  (No counterpart in the reference.) */
+ * 256 queries).  The tile width stays 64 places; the event scale is then the byte stride of a row of W2^T,
+ * 4 * roundup(P, 256) (an event's offset word is its row's byte offset), so lens_output_counts must be given exactly that
+ * ldw2 (LENS_ERR_SIZE otherwise) and F * ldw2 * 4 must stay below 2^31 (LDS tiles otherwise).  (No counterpart in the
+ * reference.) */
 int lens_output_reads_through_l2(int F, int P, int carry, int n_groups);
 
 /* The `ev_scale` lens_feature_events must be given so that lens_output_counts (same F, P, carry and split) can
  * consume its streams: the byte stride of one W2^T row in that tile (512 for the 128- and the 192-place tile,
- * whose third places sit in a plane of their own; 1 if the weights are read through L2). */
+ * whose third places sit in a plane of their own; 1 if no tile fits and the weights are read through L2; for carried
+ * state read through L2 -- lens_output_reads_through_l2 -- the byte stride of a row of W2^T at the minimal ldw2). */
 int lens_event_scale(int F, int P, int carry, int n_groups);
 
 /*

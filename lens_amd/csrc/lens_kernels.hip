@@ -1128,8 +1128,9 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 // a5-a6, carried state with the database read through L2: one wavefront per (64-place tile, stream), no LDS tile, so
 // every tile of a large database is resident at once (three 50 KB LDS tiles per CU make 100 000 places three rounds of
 // 768 wavefronts, and the rounds of a sequential stream add up).  The lone wavefront runs at the latency of its own
-// chain; its chunk loop (scripts/gen_carry_loop.py) keeps the weight rows of four chunks in flight.  Tiling and event
-// scale are those of the 64-place LDS tile; the arithmetic is integrate_chunk's.
+// chain; its chunk loop (scripts/gen_carry_loop.py) keeps the weight rows of four chunks in flight.  Tiling as for the
+// 64-place LDS tile; the event scale is the byte stride of a row of W2^T (an offset word is the row's byte offset, no
+// multiply per event: ldw2 must be the minimal roundup(P, 256)); the arithmetic is integrate_chunk's.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_output_carry_l2(OutArgs a)
 {
@@ -1139,7 +1140,6 @@ __global__ void __launch_bounds__(64) k_output_carry_l2(OutArgs a)
     const int place = tile * 64 + lane;                          // < ldw: the rows are zero padded to a multiple of 256
     const float *wb = a.w2t + (size_t)tile * 64;
     const uint32_t lane4 = (uint32_t)lane * 4u, voff = (uint32_t)(lane & 31) * 4u;
-    const uint32_t rm = (uint32_t)a.row_mul;
     const float thr = 0.99999994f;                               // 1 - 2^-24: the clip rounds it up to exactly 1.0
     float v = (place < a.P) ? a.vout[(size_t)grp * a.ldv + place] : 0.0f;
     for (int q = qs; q < qe; ++q) {
@@ -1152,7 +1152,7 @@ __global__ void __launch_bounds__(64) k_output_carry_l2(OutArgs a)
             : [v0] "+&v"(v), [c0] "=&v"(cnt), [a0] "=&v"(acc), [t] "=&v"(t), [t2] "=&v"(t2), [va] "=&v"(va), [w0] "=&v"(w0),
               [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [nch] "=&s"(nch), [soff] "=&s"(soff), [sl] "=&s"(sl),
               [sn] "=&s"(sn), [sc] "=&s"(sc), [so] "=&s"(so), [cw] "=&s"(cw), [m] "=&s"(m), [k] "=&s"(k)
-            : [ev] "s"(ev), [nwp] "s"(nwp), [wb] "s"(wb), [lane4] "v"(lane4), [voff] "v"(voff), [rm] "s"(rm), [thr] "v"(thr)
+            : [ev] "s"(ev), [nwp] "s"(nwp), [wb] "s"(wb), [lane4] "v"(lane4), [voff] "v"(voff), [thr] "v"(thr)
             : "memory", "vcc", "scc",
               "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
               "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
@@ -2058,6 +2058,8 @@ static OutPlan output_plan(int F, int P, int carry, int n_groups)
     const size_t waves = ((places + 63) / 64) * S;
     bool l2 = waves > safe;
     if (force_l2 == 0 || force_l2 == 1) l2 = force_l2 == 1;
+    // through L2 an event's offset word is the byte offset of its row of W2^T (bit 31 is the chunk's flag)
+    if ((unsigned long long)F * (((places + 255) / 256) * 256) * 4ull >= (1ull << 31)) l2 = false;
     OutPlan best{1, l2 ? OUT_LONE_L2 : OUT_LONE_LDS};
     // through L2 the wavefronts share the caches' bandwidth: 167 KB of rows per wavefront and query at the benchmark's
     // density, ~26 TB/s from L2 while the database fits the L2s, ~13 TB/s from the Infinity Cache beyond
@@ -2107,7 +2109,9 @@ int lens_output_reads_through_l2(int F, int P, int carry, int n_groups)
 
 int lens_event_scale(int F, int P, int carry, int n_groups)
 {
-    const int ppl = output_ppl(F, P, carry, n_groups);
+    const OutPlan pl = output_plan(F, P, carry, n_groups);
+    const int ppl = pl.ppl;
+    if (pl.mode == OUT_LONE_L2) return 4 * (((P > 0 ? P : 1) + 255) / 256 * 256);   // bytes of a row of W2^T at the minimal ldw2
     if (ppl == 3) return 512;   // the 128 places read as pairs; the 64 third places sit in a plane of half that stride
     return ppl ? 64 * ppl * 4 : 1;
 }
@@ -2266,9 +2270,9 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     }
     OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? (plan.mode == OUT_SHARED ? 2 : 1) : 0,
               d_counts, ldo, ntiles, n_whole, n_main, g_main, 4 * ldw2};   // row_mul: event scale 1 for the through-L2 tiles of wide layers
-    if (carry && plan.mode == OUT_LONE_L2 && (unsigned long long)F * (unsigned long long)ldw2 * 4ull < (1ull << 32)) {   // 32-bit row offsets
-        // 64-place tiles as in LDS (same event scale), but every tile's wavefront resident at once: see output_plan
-        a.row_mul = 4 * ldw2 / 256;
+    if (carry && plan.mode == OUT_LONE_L2) {
+        // every tile's wavefront resident at once (see output_plan); the streams carry byte offsets of rows at the minimal ldw2
+        if (ldw2 != (P + 255) / 256 * 256) return LENS_ERR_SIZE;
         hipLaunchKernelGGL(k_output_carry_l2, dim3((unsigned)grid), dim3(64), 0, st, a);
         return (int)hipGetLastError();
     }

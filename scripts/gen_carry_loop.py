@@ -24,7 +24,8 @@ Same f32 operations in the same order as integrate_chunk in lens_kernels.hip: bi
 Operands: [v0] membrane (in/out), [c0] spike count (out), temporaries [a0] [t] [t2] [va] (VGPR) and [w0]..[w3] (VGPR: the
 ring of stream words), scalars [nch] [soff] [sl] [sn] [sc] [so] [cw] [m] [k]; inputs [ev] stream pointer (SGPR pair),
 [nwp] address of the stream's length in words, [wb] SGPR pair: address of row 0, place 0 of this tile in W2^T, [lane4]
-4 x lane, [voff] 4 x (lane & 31), [rm] bytes of W2^T per unit of an event's offset word, [thr] 1 - 2^-24 (VGPR).
+4 x lane, [voff] 4 x (lane & 31), [thr] 1 - 2^-24 (VGPR).  The streams are written with the byte stride of a row of
+W2^T as their event scale (lens_event_scale for this layout), so an offset word needs no multiply.
 Clobbers: s[36:99] (two chunk buffers), v[64:127] (the ring of rows), vcc, scc.
 """
 import os
@@ -49,9 +50,8 @@ def gen():
         its load will fill), then the loads"""
         off = lambda i: f"s{buf + 2 * i}"
         e(f"s_and_b32 %[sc], {off(0)}, 0x7fffffff")          # EV_CHUNK_MIXED off
-        for i in range(EV_CHUNK):
-            e(f"s_mul_i32 %[sc], {'%[sc]' if i == 0 else off(i)}, %[rm]")
-            e(f"v_add_u32 {W(slot, i)}, %[sc], %[lane4]")
+        for i in range(EV_CHUNK):                             # an event's offset word is the byte offset of its row of W2^T
+            e(f"v_add_u32 {W(slot, i)}, {'%[sc]' if i == 0 else off(i)}, %[lane4]")
         for i in range(EV_CHUNK):
             e(f"global_load_dword {W(slot, i)}, {W(slot, i)}, %[wb]")
 

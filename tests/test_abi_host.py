@@ -55,7 +55,8 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     # tile widths: batch mode by cost per place; carried state (one wavefront per tile) by tiles resident at once
     assert [L.lens_output_tile_places(200, p, 0, 0) for p in (64, 1000, 100000)] == [64, 128, 192]
     assert L.lens_output_tile_places(100, 100000, 0, 0) == 256 and L.lens_output_tile_places(700, 5, 0, 0) == 0
-    assert L.lens_output_tile_places(200, 100000, 1, 1) == 64 and L.lens_event_scale(200, 100000, 1, 1) == 256
+    assert L.lens_output_tile_places(200, 100000, 1, 1) == 64 and L.lens_event_scale(200, 1000, 1, 1) == 256
+    assert L.lens_event_scale(200, 100000, 1, 1) == 4 * 100096      # read through L2: an offset word is the row's byte offset
     # carried state reads the database through L2 once its (64-place tile, stream) wavefronts outnumber the tiles the
     # CUs' LDS surely holds (one less than fits per CU: 2 x 256 at F = 200); the batch mode never does for layers that fit a tile
     rd = L.lens_output_reads_through_l2

@@ -2313,6 +2313,7 @@ int lens_forward_counts_static(const uint8_t *d_frames, int Q, int HW, const int
     if (!d_w2t || !d_counts || (carry && !d_vout)) return LENS_ERR_NULL;
     if (P <= 0 || ldw2 < P || ldo < P || (carry && ldv < P)) return LENS_ERR_SIZE;
     if ((ldw2 & 255) || ((uintptr_t)d_w2t & 15)) return LENS_ERR_ALIGN;
+    if (carry && output_plan(F, P, carry, split).mode == OUT_LONE_L2 && ldw2 != (P + 255) / 256 * 256) return LENS_ERR_SIZE;
     if (int e = lens_feature_events(d_frames, Q, HW, d_sel, N, d_codes, T, d_w1t, F, ldw1, d_vfeat, split, carry,
                                     events, (int)cap, nwords, lens_event_scale(F, P, carry, split), nullptr, nullptr, stream))
         return e;

@@ -45,6 +45,8 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     assert L.lens_output_counts(p, 32, p, 1, p, 4, 10, 100, None, 10, 1, 0, p, 10, None) == -4   # ldw2 % 256
     assert L.lens_output_counts(p, 16, p, 1, p, 4, 10, 256, None, 10, 1, 0, p, 10, None) == -2   # streams hold whole 32-word chunks
     assert L.lens_output_counts(p, 48, p, 1, p, 4, 10, 256, None, 10, 1, 0, p, 10, None) == -2
+    # carried state read through L2: the streams carry byte offsets of rows at the minimal ldw2, any other is refused
+    assert L.lens_output_counts(p, 32, p, 1, p, 200, 100000, 100352, p, 100000, 1, 1, p, 100000, None) == -2
     assert L.lens_amd_strerror(-2).decode().startswith("a size")
     assert L.lens_event_capacity_words(250, 200) == 100000
     assert L.lens_event_capacity_words(3, 0) == 32

@@ -1004,7 +1004,6 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         qs = (int)(((long long)grp * a.Q) / a.n_groups);
         qe = (int)(((long long)(grp + 1) * a.Q) / a.n_groups);
     }
-    if (a.carry == 1 && wave != 0) return;   // a carried stream is sequential: one wavefront per (tile, stream)
     const uint32_t lane_off = (uint32_t)lane * (PPL == 3 ? 8 : PPL * 4);
     {
         const int nq = qe - qs;
@@ -1046,6 +1045,9 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
             }
             __syncthreads();
         }
+        // a carried stream is sequential: one wavefront per (tile, stream) walks it; the workgroup's other wavefronts only
+        // helped to stage the tile (a lone wavefront takes ~15 us for 50 KB, every launch of a pipelined stream again)
+        if (a.carry == 1 && wave != 0) return;
         const int pl = p0 + lane * PPL;   // first place of this lane (contiguous layouts)
         int place[PPL];
 #pragma unroll
@@ -2219,7 +2221,7 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
         threads = 64 * (n_groups < 16 ? n_groups : 16);
         grid = ntiles * ((n_groups + 15) / 16);
     } else if (carry) {
-        threads = 64;
+        threads = plan.mode == OUT_LONE_LDS && ppl ? 256 : 64;   // lone wavefronts on LDS tiles: three more to stage the tile
         grid = ntiles * n_groups;
     } else {
         threads = 1024;

@@ -955,7 +955,9 @@ __device__ __forceinline__ void output_loop_asm(const uint32_t *ev, const uint32
 #undef LENS_OUT_JUMP_SGPRS
 #undef LENS_OUT_COMMON_IN
 
-template <int PPL, bool W_LDS>
+// LONE: the instantiation for carried state with one wavefront per (tile, stream) (a.carry == 1 on an LDS tile): kept
+// apart so that its staging code does not touch the batch kernel's code generation.
+template <int PPL, bool W_LDS, bool LONE = false>
 __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1012,13 +1014,40 @@ __global__ void __launch_bounds__(1024) k_output_counts(OutArgs a)
         if constexpr (W_LDS) {
             float4 *dst = reinterpret_cast<float4 *>(smem);
             const int n4 = a.F * (PT / 4);
-            for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            // carried state, one wavefront per tile: eight independent 16-byte loads in flight per thread, then their stores
+            // (one load and one store at a time cost such a workgroup ~10 us per launch, and a pipelined stream launches
+            // every 16 queries); the batch mode keeps the plain loop below -- its staging is amortised over thousands of queries
+            constexpr int SU = 8;
+            for (int i0 = threadIdx.x; LONE && i0 < n4; i0 += blockDim.x * SU) {
+                float4 x[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = i0 + u * blockDim.x;
+                    const int f = i / (PT / 4), c = i - f * (PT / 4);
+                    x[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    // (a 192-place tile may reach past the padded row: ldw is a multiple of 256, not of 192)
+                    if (i < n4 && (PPL != 3 || p0 + c * 4 < a.ldw))
+                        x[u] = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = i0 + u * blockDim.x;
+                    if (i >= n4) continue;
+                    if constexpr (PPL == 3) {
+                        // places 0..127 of the row -> pairs plane (behind the F x 256 bytes of the thirds plane), 128..191 -> thirds
+                        const int f = i / (PT / 4), c = i - f * (PT / 4);
+                        unsigned char *d = c < 32 ? smem + (size_t)a.F * 256 + (size_t)f * 512 + c * 16 : smem + (size_t)f * 256 + (c - 32) * 16;
+                        *reinterpret_cast<float4 *>(d) = x[u];
+                    } else {
+                        dst[i] = x[u];
+                    }
+                }
+            }
+            for (int i = threadIdx.x; !LONE && i < n4; i += blockDim.x) {
                 const int f = i / (PT / 4), c = i - f * (PT / 4);
                 if constexpr (PPL == 3) {
-                    // a 192-place tile may reach past the padded row (ldw is a multiple of 256, not of 192)
                     float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     if (p0 + c * 4 < a.ldw) x = *reinterpret_cast<const float4 *>(a.w2t + (size_t)f * a.ldw + p0 + c * 4);
-                    // places 0..127 of the row -> pairs plane (behind the F x 256 bytes of the thirds plane), 128..191 -> thirds
                     unsigned char *d = c < 32 ? smem + (size_t)a.F * 256 + (size_t)f * 512 + c * 16 : smem + (size_t)f * 256 + (c - 32) * 16;
                     *reinterpret_cast<float4 *>(d) = x;
                 } else {
@@ -1865,13 +1894,13 @@ size_t fire_lds_bytes(int T, int F, int cap_words)
     return 2 * (((size_t)T * NW * 12 + 7) & ~(size_t)7) + FIRE_HELPERS * ((2 * (size_t)T + 1) + mixed_words) * 4;
 }
 
-template <int PPL, bool W_LDS>
+template <int PPL, bool W_LDS, bool LONE = false>
 int launch_output(const OutArgs &a, int threads, int grid, hipStream_t st)
 {
     // carried state: one wavefront per workgroup, no query ranking -- only the (unused) counter word behind the tile,
     // so that three 50 KB tiles still fit one CU
     const size_t lds = (W_LDS ? (size_t)a.F * 64 * PPL * 4 : 0) + (a.carry ? OUT_BOOK_CARRY_BYTES : OUT_BOOK_BYTES);
-    auto k = k_output_counts<PPL, W_LDS>;
+    auto k = k_output_counts<PPL, W_LDS, LONE>;
     if constexpr (PPL == 3) {
         // The assembly loop reads the third places relative to LDS address 0: the kernel must not own static LDS
         // (a __shared__ variable added to it would shift the dynamic block and silently break the addressing).
@@ -2278,6 +2307,7 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
         hipLaunchKernelGGL(k_output_carry_l2, dim3((unsigned)grid), dim3(64), 0, st, a);
         return (int)hipGetLastError();
     }
+    if (carry && plan.mode == OUT_LONE_LDS && ppl == 1) return launch_output<1, true, true>(a, threads, grid, st);
     switch (ppl) {
     case 4: return launch_output<4, true>(a, threads, grid, st);
     case 3: return launch_output<3, true>(a, threads, grid, st);

@@ -534,7 +534,8 @@ def main():
         if not a.no_cpu_baseline:
             gi, gv = last["res"]
             base, parity = cpu_baseline_and_parity(frames_cpu, w1, w2, last.get("counts"), gi, gv)
-            line["cpu_baseline"] = base
+            if world == 1:                          # with peers spinning in the final barrier the host timing means little
+                line["cpu_baseline"] = base
             line["parity"] = parity
         print(json.dumps(line))
     if grouped:

@@ -250,7 +250,8 @@ def carried_rates(eng, frames, what):
         carry[f"streams_{n_streams}"] = {"value": qc / dtc, "unit": "query event-frames/s", "ms_per_batch": dtc * 1e3,
                                          "queries": qc, "output_tile_places": eng.tile_places(True),
                                          "output_layout": ("batch", "lone wavefronts on LDS tiles", "lone wavefronts through L2",
-                                                           "LDS tiles shared by 16 streams")[eng.layout(True)]}
+                                                           "LDS tiles shared by 16 streams")[eng.layout(True)],
+                                         "tail_places_on_lone_tiles": eng.tail_places(True)}
     eng.reset_state()
     carry["note"] = ("reference semantics: membrane state carried across queries, each stream strictly sequential in "
                      f"the query index; {what}; streams_1 is the drop-in for lens/run_model.py:229-246")

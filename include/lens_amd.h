@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LENS_AMD_ABI_VERSION 10
+#define LENS_AMD_ABI_VERSION 11
 
 /* Rows of slack behind the currents buffer of lens_feature_currents / lens_feature_fire. */
 #define LENS_FIRE_SLACK_ROWS 32
@@ -120,6 +120,13 @@ int lens_output_tile_places(int F, int P, int carry, int n_groups);
 #define LENS_LAYOUT_LONE_L2 2
 #define LENS_LAYOUT_SHARED 3
 int lens_output_layout(int F, int P, int carry, int n_groups);
+
+/* LENS_LAYOUT_SHARED only, else 0: the number of places at the end of the database that lens_output_counts runs as a
+ * second launch of lone wavefronts on 128-place LDS tiles (same streams, same event scale).  The workgroups of a launch
+ * all take the same time, so a few wide tiles beyond whole rounds of the CUs would cost a whole round more (100 000
+ * places as 16 streams: 521 tiles of 192 = 2.04 rounds); where the cost model says it pays, the wide tiles cover whole
+ * rounds and the rest is this tail.  LENS_AMD_CARRY_TAIL=0 switches it off.  (No counterpart in the reference.) */
+int lens_output_tail_places(int F, int P, int carry, int n_groups);
 
 /* 1 when lens_output_counts reads W2^T through L2 for these arguments instead of staging tiles in LDS: no tile fits
  * (lens_output_tile_places == 0), or carried state with more (64-place tile, stream) wavefronts than the CUs' LDS surely

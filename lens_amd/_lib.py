@@ -39,6 +39,7 @@ SIGNATURES = {
     "lens_output_tile_places": (_i, [_i, _i, _i, _i]),
     "lens_output_reads_through_l2": (_i, [_i, _i, _i, _i]),
     "lens_output_layout": (_i, [_i, _i, _i, _i]),
+    "lens_output_tail_places": (_i, [_i, _i, _i, _i]),
     "lens_event_scale": (_i, [_i, _i, _i, _i]),
     "lens_build_active_steps": (_i, [_c_p, _i, _i, _c_p]),
     "lens_feature_events": (_i, [_c_p, _i, _i, _c_p, _i, _c_p, _i, _c_p, _i, _i, _c_p, _i, _i,
@@ -61,7 +62,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class LensAmdError(RuntimeError):

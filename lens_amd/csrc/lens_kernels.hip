@@ -2050,9 +2050,14 @@ size_t lens_event_capacity_words(int T, int F)
 //             several streams on a large database (100 000 places x 16 streams, ms per 256 queries: 5.14 as lone
 //             wavefronts through L2, 1.52 shared; x 4: 5.18 / 4.48; x 2: 5.51 / 8.56; 12 501 places x 32: 0.37 / 0.21;
 //             1000 places x 16: 0.28 on lone LDS tiles / 0.35 shared -- scripts/experiments/carry_layouts.py).
+//             The workgroups of a launch all take the same time, so a grid of a few workgroups more than whole rounds of
+//             the CUs costs a whole round more (100 000 places x 16 streams: 521 tiles, 2.04 rounds).  Where it pays, the
+//             wide tiles cover whole rounds only and the remaining places run as a second launch of lone wavefronts on
+//             128-place LDS tiles (same event scale as the 128- and 192-place shared tiles, 18.5 us per query-step, one
+//             100 KB tile per CU): OutPlan::main_tiles.  LENS_AMD_CARRY_TAIL=0 switches that off.
 // LENS_AMD_CARRY_L2=0/1 and LENS_AMD_CARRY_SHARED=0/1/2/3/4 force a choice (tuning and tests; read at every call).
 enum { OUT_BATCH = 0, OUT_LONE_LDS = 1, OUT_LONE_L2 = 2, OUT_SHARED = 3 };
-struct OutPlan { int ppl; int mode; };
+struct OutPlan { int ppl; int mode; int main_tiles = 0; };   // main_tiles > 0 (SHARED only): that many wide tiles, the rest as a tail (below)
 
 static int output_ppl_batch(int F, int P)
 {
@@ -2083,6 +2088,8 @@ static OutPlan output_plan(int F, int P, int carry, int n_groups)
     const char *env_l2 = getenv("LENS_AMD_CARRY_L2"), *env_shared = getenv("LENS_AMD_CARRY_SHARED");
     const int force_l2 = env_l2 ? atoi(env_l2) : -1;
     const int force_shared = env_shared ? atoi(env_shared) : -1;    // 0: never, 1: always (cheapest width), 2..4: always, that many places per lane
+    const char *env_tail = getenv("LENS_AMD_CARRY_TAIL");
+    const bool tail_allowed = !(env_tail && atoi(env_tail) == 0);
     // lone wavefronts on 64-place tiles
     const size_t per_cu = (size_t)LDS_BUDGET / (tile1 + 512);            // allocation granularity
     const size_t safe = NUM_CUS * (per_cu <= 2 ? 1 : per_cu > 33 ? 32 : per_cu - 1);
@@ -2110,10 +2117,21 @@ static OutPlan output_plan(int F, int P, int carry, int n_groups)
         const size_t wgs = ((places + pt - 1) / pt) * ((S + 15) / 16);
         const double per_simd = (double)((wpw + 3) / 4);
         const double t = c.lone > c.busy * per_simd / 4.0 ? c.lone : c.busy * per_simd / 4.0;
-        const double cost = t * (double)((wgs + NUM_CUS - 1) / NUM_CUS);
+        double cost = t * (double)((wgs + NUM_CUS - 1) / NUM_CUS);
+        // whole rounds on the wide tiles + the remaining places as lone wavefronts on 128-place tiles (one per CU)
+        int main_tiles = 0;
+        const size_t sg = (S + 15) / 16;
+        // wide tiles in whole rounds; an even number of 192-place tiles, so that the tail starts on a multiple of 128 places
+        // (its last tile then ends within the padded row of W2^T)
+        const size_t whole = ((wgs / NUM_CUS) * NUM_CUS / sg) & ~(size_t)(c.ppl == 3 ? 1 : 0);
+        if (tail_allowed && c.ppl <= 3 && whole > 0 && whole * pt < places && (size_t)F * 512 + 512 <= (size_t)LDS_BUDGET) {
+            const size_t tail_wgs = ((places - whole * pt + 127) / 128) * S;
+            const double split = t * (double)((whole * sg + NUM_CUS - 1) / NUM_CUS) + 18.5 * (double)((tail_wgs + NUM_CUS - 1) / NUM_CUS);
+            if (split < 0.95 * cost) { cost = split; main_tiles = (int)whole; }
+        }
         // (a predicted gain below 10 % is within the model's error: the lone wavefronts stay)
         if (force_shared >= 1 ? (best.mode != OUT_SHARED || cost < best_cost) : cost < (best.mode == OUT_SHARED ? 1.0 : 0.9) * best_cost) {
-            best = {c.ppl, OUT_SHARED};
+            best = {c.ppl, OUT_SHARED, main_tiles};
             best_cost = cost;
         }
     }
@@ -2130,6 +2148,12 @@ int lens_output_tile_places(int F, int P, int carry, int n_groups)
 int lens_output_layout(int F, int P, int carry, int n_groups)
 {
     return output_plan(F, P, carry, n_groups).mode;
+}
+
+int lens_output_tail_places(int F, int P, int carry, int n_groups)
+{
+    const OutPlan pl = output_plan(F, P, carry, n_groups);
+    return pl.mode == OUT_SHARED && pl.main_tiles ? P - pl.main_tiles * 64 * pl.ppl : 0;
 }
 
 int lens_output_reads_through_l2(int F, int P, int carry, int n_groups)
@@ -2248,7 +2272,7 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     int threads, grid, n_whole = 0, n_main = NUM_CUS, g_main = 1;
     if (carry && plan.mode == OUT_SHARED) {
         threads = 64 * (n_groups < 16 ? n_groups : 16);
-        grid = ntiles * ((n_groups + 15) / 16);
+        grid = (plan.main_tiles ? plan.main_tiles : ntiles) * ((n_groups + 15) / 16);
     } else if (carry) {
         threads = plan.mode == OUT_LONE_LDS && ppl ? 256 : 64;   // lone wavefronts on LDS tiles: three more to stage the tile
         grid = ntiles * n_groups;
@@ -2301,6 +2325,23 @@ int lens_output_counts(const uint32_t *d_events, int cap_words, const uint32_t *
     }
     OutArgs a{d_events, cap_words, d_nwords, Q, d_w2t, F, P, ldw2, d_vout, ldv, n_groups, carry ? (plan.mode == OUT_SHARED ? 2 : 1) : 0,
               d_counts, ldo, ntiles, n_whole, n_main, g_main, 4 * ldw2};   // row_mul: event scale 1 for the through-L2 tiles of wide layers
+    if (carry && plan.mode == OUT_SHARED && plan.main_tiles) {
+        // whole rounds of the CUs on the wide shared tiles, then the remaining places (columns p_main ... P - 1 of W2^T, of
+        // the membranes and of the counts) as lone wavefronts on 128-place tiles: same streams, same event scale
+        const int p_main = plan.main_tiles * pt;
+        OutArgs m = a, t = a;
+        m.P = p_main;
+        m.ntiles = plan.main_tiles;
+        const int e = ppl == 3 ? launch_output<3, true>(m, threads, grid, st) : launch_output<2, true>(m, threads, grid, st);
+        if (e) return e;
+        t.w2t += p_main;
+        t.vout += p_main;
+        t.counts += p_main;
+        t.P = P - p_main;
+        t.ntiles = (t.P + 127) / 128;
+        t.carry = 1;
+        return launch_output<2, true, true>(t, 256, t.ntiles * n_groups, st);
+    }
     if (carry && plan.mode == OUT_LONE_L2) {
         // every tile's wavefront resident at once (see output_plan); the streams carry byte offsets of rows at the minimal ldw2
         if (ldw2 != (P + 255) / 256 * 256) return LENS_ERR_SIZE;

@@ -159,6 +159,11 @@ class LensEngine:
         3 wide LDS tiles shared by 16 carried streams."""
         return int(_lib.lib().lens_output_layout(self.F, self.P, int(bool(carry)), self.n_streams if carry else 0))
 
+    def tail_places(self, carry=False):
+        """Places at the end of the database that the shared-tile layout runs as a second launch of lone wavefronts on
+        128-place tiles (lens_output_tail_places; 0: none)."""
+        return int(_lib.lib().lens_output_tail_places(self.F, self.P, int(bool(carry)), self.n_streams if carry else 0))
+
     def reads_through_l2(self, carry=False):
         """True when the output layer reads the database through L2 instead of LDS tiles in this mode: no tile fits, or
         carried state with more (tile, stream) wavefronts than LDS-resident tiles (lens_output_reads_through_l2)."""

@@ -71,6 +71,11 @@ def test_argument_errors_are_negative_statuses_without_touching_the_gpu(L):
     assert L.lens_output_tile_places(200, 100000, 1, 16) == 192 and L.lens_event_scale(200, 100000, 1, 16) == 512
     assert L.lens_output_tile_places(200, 12501, 1, 32) == 128 and lay(700, 5, 1, 4) == 1
     assert rd(200, 100000, 0, 0) == 0 and rd(700, 5, 0, 0) == 1 and rd(700, 5, 1, 1) == 1
+    # shared tiles cover whole rounds of the 256 CUs; the places beyond run as lone wavefronts on 128-place tiles
+    tail = L.lens_output_tail_places
+    assert [tail(200, 100000, 1, g) for g in (1, 4, 16, 64)] == [0, 100000 - 512 * 192, 100000 - 512 * 192, 0]
+    assert tail(200, 100000, 0, 0) == 0 and tail(200, 12501, 1, 32) == 0 and tail(200, 98304, 1, 16) == 0
+    assert tail(200, 512 * 192 + 300, 1, 16) == 300 and tail(200, 256 * 192 + 300, 1, 16) == 0    # two rounds of 128-place tiles there
 
 
 def test_active_step_table_counts_input_spikes(L):

@@ -171,6 +171,34 @@ def test_carried_streams_on_shared_tiles_match_oracle(O):
         assert np.array_equal(out2[s], O.forward(both, 10, U, w1, w2, carry=True, skip_zero=True)[2]), s
 
 
+def test_shared_tiles_in_whole_rounds_and_a_tail_of_lone_wavefronts_match_oracle(O, monkeypatch):
+    """16 carried streams on a database of two wide tiles more than one round of the CUs: the 256 tiles of the round
+    are shared by the streams, the last 300 places run as a second launch of lone wavefronts on 128-place tiles (same
+    streams).  Counts equal the oracle's run on each stream over two calls, and the run without the tail."""
+    from lens_amd.synthetic import synthetic_frames, synthetic_database
+    w1, w2p = pretrained_example()
+    P, S, T = 256 * 192 + 300, 16, 60
+    w2 = synthetic_database(w2p, P).numpy()
+    frames = synthetic_frames(3 * S, 128, seed=29)
+    monkeypatch.setenv("LENS_AMD_CARRY_SHARED", "3")       # (the cost model would take two rounds of 128-place tiles here)
+    eng = _engine(w1, w2, 128, 10, T=T)
+    eng.reset_state(n_streams=S)
+    assert eng.layout(carry=True) == 3 and eng.tile_places(carry=True) == 192 and eng.tail_places(carry=True) == 300
+    out = eng.forward_counts(frames[:2 * S].cuda(), carry=True).cpu().numpy()
+    out2 = eng.forward_counts(frames[2 * S:].cuda(), carry=True).cpu().numpy()
+    U = O.rand_U(T, 128 * 128)
+    f = frames.numpy()
+    for s in range(S):
+        both = np.concatenate([f[s * 2:(s + 1) * 2], f[2 * S + s:2 * S + s + 1]])
+        ref = O.forward(both, 10, U, w1, w2, carry=True, skip_zero=True)
+        assert np.array_equal(out[2 * s:2 * s + 2], ref[:2]) and np.array_equal(out2[s], ref[2]), s
+    assert out[:, -300:].sum() > 0 and out[:, :-300].sum() > 0
+    monkeypatch.setenv("LENS_AMD_CARRY_TAIL", "0")
+    eng.reset_state(n_streams=S)
+    assert eng.layout(carry=True) == 3 and eng.tail_places(carry=True) == 0
+    assert np.array_equal(eng.forward_counts(frames[:2 * S].cuda(), carry=True).cpu().numpy(), out)
+
+
 def test_odd_sizes_and_wide_layers(O):
     """Ragged sizes: N=49 (one partial register), F=63, P=641 already covered by sunset; here a wide
     feature layer (F=520 -> 16 registers/lane rounds to the 32 variant) and N=144."""
